@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REAL reference, compiled into oracle/_ref.
+
+Run in the build container only (needs /root/reference):
+
+    make -C oracle ref && OMP_NUM_THREADS=1 python tests/golden/make_golden.py
+
+OMP_NUM_THREADS=1 is required: the reference seeds one mt19937 per OpenMP thread
+(BatchedMCTS.h:68-84), so seeded streams are only machine-independent with one thread.
+
+Nothing from the reference is copied: its compiled extensions are imported from
+oracle/_ref/native, its unmodified Python (player.py, game.py, MCTS_cpp.py, Network.py) from
+/root/reference through a namespace-package overlay.  The committed
+outputs are data: seeded inputs and the reference's outputs for them, plus the tensors of
+the checkpoint the reference ships (params/Connect4/001/current/model.pt, loaded with
+weights_only=True) so the GPU box can evaluate the same network.
+"""
+import os
+import subprocess
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("AZ_REFERENCE", "/root/reference")
+assert os.environ.get("OMP_NUM_THREADS") == "1", "run with OMP_NUM_THREADS=1"
+
+sys.path[:0] = [os.path.join(ROOT, "oracle", "_ref", "native"), REF, os.path.join(ROOT, "tests")]
+numba = types.ModuleType("numba")
+numba.njit = lambda *a, **k: (lambda f: f)
+sys.modules["numba"] = numba
+
+import scenarios as S                      # noqa: E402
+from src import mcts_cpp                   # noqa: E402  (compiled reference)
+from src.env_cpp.connect4 import Env       # noqa: E402  (compiled reference)
+from src.MCTS_cpp import BatchedMCTS       # noqa: E402  (reference python, unmodified)
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+# ------------------------------------------------------------------ rng_std
+def gen_rng():
+    exe = "/tmp/std_rng_dump"
+    subprocess.check_call(["g++", "-std=c++20", "-O3", "-march=native",
+                           os.path.join(HERE, "std_rng_dump.cpp"), "-o", exe])
+    raw = subprocess.check_output([exe])
+    per = 16 + 1024 + 1024 + 4 * 200 * 7 + 1
+    a = np.frombuffer(raw, np.uint32).reshape(3, per)
+    save("rng_std",
+         seeds=np.array([0, 1234, 20071], np.uint32),
+         alphas=np.array([0.3, 0.03, 1.0, 2.5], np.float32),
+         mt=a[:, :16].copy(),
+         bits=a[:, 16:1040].astype(np.int32),
+         ranged=a[:, 1040:2064].astype(np.int32),
+         gamma=a[:, 2064:2064 + 5600].copy().view(np.float32).reshape(3, 4, 200, 7),
+         tail=a[:, -1].copy())
+
+
+# ------------------------------------------------------------------ G1 game logic
+def gen_g1():
+    rng = np.random.default_rng(101)
+    rec = {k: [] for k in ("board", "turn", "winner", "full", "done", "mask", "state",
+                           "mirror", "mirror_state", "action", "game")}
+    for g in range(160):
+        e = Env()
+        bias = rng.integers(0, 3)      # 0 uniform, 1 prefer few columns (fast wins), 2 fill up
+        while True:
+            valid = e.valid_move()
+            rec["board"].append(np.asarray(e.board, np.float32).astype(np.int8))
+            rec["turn"].append(e.turn)
+            rec["winner"].append(e.winPlayer())
+            rec["full"].append(e.check_full())
+            rec["done"].append(e.done())
+            rec["mask"].append(np.array(e.valid_mask(), np.uint8))
+            rec["state"].append(e.current_state()[0].astype(np.int8))
+            m = e.apply_symmetry(1)
+            rec["mirror"].append(np.asarray(m.board, np.float32).astype(np.int8))
+            rec["mirror_state"].append(m.current_state()[0].astype(np.int8))
+            rec["game"].append(g)
+            if e.done():
+                rec["action"].append(-1)
+                break
+            if bias == 1:
+                pref = [c for c in valid if c in (2, 3, 4)] or valid
+                a = int(rng.choice(pref))
+            elif bias == 2:
+                a = int(valid[(len(rec["game"]) * 3) % len(valid)])
+            else:
+                a = int(rng.choice(valid))
+            rec["action"].append(a)
+            e.step(a)
+    out = {k: np.array(v) for k, v in rec.items()}
+    # board setter / constructor: turn inferred from parity (env_common.h:55-70), including a
+    # board with a floating piece (sync_from_board stops at the first gap, Connect4.h:109-121)
+    odd = np.zeros((4, 6, 7), np.float32)
+    odd[0, 5, 3] = 1
+    odd[1, 5, 3] = 1; odd[1, 5, 4] = -1
+    odd[2, 5, 0] = 1; odd[2, 3, 0] = -1                      # floating piece above a gap
+    odd[3, 5, :] = [1, -1, 1, -1, 1, -1, 1]
+    setter = []
+    for b in odd:
+        e = Env(b)
+        setter.append(dict(turn=e.turn, board=np.asarray(e.board), mask=e.valid_mask(),
+                           winner=e.winPlayer()))
+    save("g1_game_logic", **{k: v.astype(np.int8) if v.dtype != np.bool_ else v.astype(np.uint8)
+                             for k, v in out.items()},
+         setter_in=odd.astype(np.int8),
+         setter_turn=np.array([s["turn"] for s in setter], np.int8),
+         setter_board=np.array([s["board"] for s in setter]).astype(np.int8),
+         setter_mask=np.array([s["mask"] for s in setter], np.uint8))
+
+
+# ------------------------------------------------------------------ G2-G5 search scenarios
+def gen_search():
+    for name in S.SEARCH_SCENARIOS:
+        r = S.run_search_scenario(mcts_cpp.BatchedMCTS_Connect4, name)
+        save(name, **r)
+
+
+# ------------------------------------------------------------------ G2 hand-built single calls
+def gen_g2():
+    """One search_batch / backprop_batch round trip on hand-built positions; raw outputs."""
+    b = np.zeros((6, 6, 7), np.int8)
+    t = np.ones(6, np.int32)
+    # 0: empty board; 1: P1 has three in a row on the bottom (win available at col 3)
+    b[1, 5, 0:3] = 1; b[1, 4, 0:3] = -1; t[1] = 1
+    # 2: P2 to move, fresh tree (root turn quirk)
+    b[2, 5, 3] = 1; t[2] = -1
+    # 3: root already won by P1 (terminal root), P2 "to move"
+    b[3, 5, 0:4] = 1; b[3, 4, 0:3] = -1; t[3] = -1
+    # 4: full board draw pattern
+    pat = np.array([[1, 1, -1, -1, 1, 1, -1]] * 2 + [[-1, -1, 1, 1, -1, -1, 1]] * 2 +
+                   [[1, 1, -1, -1, 1, 1, -1]] * 2, np.int8)
+    b[4] = pat; t[4] = 1
+    # 5: one empty cell left (col 6 top), move fills the board
+    b[5] = pat; b[5, 0, 6] = 0; t[5] = -1
+    m = mcts_cpp.BatchedMCTS_Connect4(6)
+    S.apply_cfg(m, S.DET_CFG)
+    outs = {}
+    for it in range(6):
+        res = m.search_batch(b, t)
+        for j, nm in enumerate(("lb", "td", "t1", "t2", "it", "lt", "vm")):
+            outs[f"s{it}_{nm}"] = res[j]
+        lb, td, t1, t2, itm, lt, vm = res
+        pr, wdl, ml = S.hash_eval(lb, lt)
+        d, p1, p2 = S.rel_to_abs(wdl, lt)
+        nt = ~itm.astype(bool)
+        probs = np.where(nt[:, None], pr * vm, 0).astype(np.float32)
+        m.backprop_batch(probs, np.where(nt, d, td), np.where(nt, p1, t1), np.where(nt, p2, t2),
+                         np.where(nt, ml, 0).astype(np.float32), itm)
+        outs[f"s{it}_counts"] = np.array(m.get_all_counts(), np.int32)
+        outs[f"s{it}_stats"] = m.get_all_root_stats()
+    # VL round with K=3 then remove_all_vl twice (idempotence), stats must be unchanged by it
+    res = m.search_batch_vl(3, b, t)
+    for j, nm in enumerate(("lb", "td", "t1", "t2", "it", "lt", "sy", "vm")):
+        outs[f"vl_{nm}"] = res[j]
+    m.remove_all_vl(3); m.remove_all_vl(3)
+    outs["vl_removed_stats"] = m.get_all_root_stats()
+    res2 = m.search_batch(b, t)     # same leaves as a clean tree would give
+    outs["after_remove_lb"] = res2[0]; outs["after_remove_it"] = res2[4]
+    save("g2_single_calls", boards=b, turns=t, **outs)
+
+
+# ------------------------------------------------------------------ G6 wrapper
+def gen_g6():
+    rng = np.random.default_rng(66)
+    boards, turns = S.random_openings(rng, 24, 8)
+    out = {}
+    for tag, cache, K, seed in (("nocache_k4", 0, 4, 5), ("cache_k4", 4096, 4, 5),
+                                ("nocache_k1", 0, 1, 9), ("cache_k1", 64, 1, 9)):
+        w = BatchedMCTS(24, c_init=1.4, c_base=250, alpha=0.3, n_playout=50, game_name="Connect4",
+                        cache_size=cache, noise_epsilon=0.25, fpu_reduction=0.2, use_symmetry=True,
+                        mlh_slope=0.1, mlh_cap=0.2)
+        w.seed(seed)
+        pv = S.HashPV()
+        b, t = boards.copy(), turns.copy()
+        cs, ss = [], []
+        for ply in range(3):
+            w.batch_playout(pv, b, t, vl_batch=K)
+            c = w.get_visits_count()
+            cs.append(c.astype(np.int32)); ss.append(w.mcts.get_all_root_stats())
+            acts = np.argmax(c, 1).astype(np.int32)
+            w.prune_roots(acts)
+            for i in range(24):
+                if not S.np_done(b[i]) and b[i][0, acts[i]] == 0:
+                    S.np_drop(b[i], int(acts[i]), int(t[i])); t[i] = -t[i]
+        out[f"{tag}_counts"] = np.stack(cs); out[f"{tag}_stats"] = np.stack(ss)
+        out[f"{tag}_calls"] = np.array(pv.calls, np.int32)
+        if cache:
+            out[f"{tag}_cache_len"] = np.array([len(w.cache)], np.int32)
+    save("g6_wrapper", boards=boards, turns=turns, **out)
+
+
+# ------------------------------------------------------------------ G9 rollout search
+def gen_rollout():
+    rng = np.random.default_rng(77)
+    boards, turns = S.random_openings(rng, 12, 12)
+    w = BatchedMCTS(12, c_init=4, c_base=500, alpha=0, n_playout=120, game_name="Connect4",
+                    noise_epsilon=0.0, fpu_reduction=0.0, use_symmetry=False)   # player.py:84-88
+    w.seed(3)
+    w.rollout_playout(boards, turns)
+    save("g9_rollout", boards=boards, turns=turns, counts=w.get_visits_count().astype(np.int32),
+         stats=w.mcts.get_all_root_stats())
+
+
+# ------------------------------------------------------------------ G7 network
+def gen_g7():
+    import torch
+    from src.environments.Connect4.Network import CNN
+    torch.manual_seed(0)
+    net = CNN(lr=1e-3, device="cpu")
+    net.eval()
+    sd = torch.load(os.path.join(REF, "params/Connect4/001/current/model.pt"),
+                    weights_only=True, map_location="cpu")
+    rng = np.random.default_rng(7)
+    boards, turns = S.random_openings(rng, 256, 30)
+    planes = np.stack([(boards == turns[:, None, None]), (boards == -turns[:, None, None]),
+                       np.ones_like(boards) * turns[:, None, None]], 1).astype(np.float32)
+    masks = (boards[:, 0, :] == 0)
+    p0, w0, m0 = net.predict(planes, masks)          # random init: zero-init heads
+    net.load_state_dict(sd, strict=True)
+    p1, w1, m1 = net.predict(planes, masks)
+    with torch.no_grad():
+        lp, lv, st = net(torch.from_numpy(planes), action_mask=torch.from_numpy(masks))
+    save("g7_network", boards=boards, turns=turns, masks=masks.astype(np.uint8),
+         init_probs=p0, init_wdl=w0, init_ml=m0,
+         ckpt_probs=p1, ckpt_wdl=w1, ckpt_ml=m1,
+         ckpt_logp=lp.numpy(), ckpt_logv=lv.numpy(), ckpt_steps=st.numpy())
+    save("g7_checkpoint_weights", **{k: v.numpy() for k, v in sd.items()})
+
+
+# ------------------------------------------------------------------ G8 self-play harness
+def gen_g8():
+    from src.game import Game
+    from src.player import AlphaZeroPlayer
+    pv = S.HashPV()
+    np.random.seed(11)
+    player = AlphaZeroPlayer(pv, n_envs=8, c_init=1.4, c_base=160, n_playout=32, alpha=0.3,
+                             is_selfplay=1, noise_epsilon=0.25, fpu_reduction=0.2,
+                             use_symmetry=True, mlh_slope=0.1, mlh_cap=0.2, vl_batch=4)
+    player.mcts.seed(21)
+    game = Game(Env())
+    data = game.batch_self_play(player, 8, temperature=1.0, temp_decay_moves=6, temp_endgame=0,
+                                td_steps=2)
+    out = {}
+    for i, (winner, play) in enumerate(data):
+        out[f"g{i}_winner"] = np.array([winner], np.int32)
+        for j, nm in enumerate(("state", "prob", "z", "steps", "aux", "root_wdl", "mask", "fut")):
+            out[f"g{i}_{nm}"] = np.array([np.asarray(tup[j]) for tup in play])
+    save("g8_selfplay", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["rng", "g1", "g2", "search", "g6", "rollout", "g7", "g8"]
+    fns = dict(rng=gen_rng, g1=gen_g1, g2=gen_g2, search=gen_search, g6=gen_g6,
+               rollout=gen_rollout, g7=gen_g7, g8=gen_g8)
+    for w in which:
+        fns[w]()
