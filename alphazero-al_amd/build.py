@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Build the native pieces in-tree (no install step; the .so files travel with the repo).
+
+    lib/libaz_mcts.so          HIP engine + C ABI (include/az_mcts.h), hipcc --offload-arch=gfx950
+    src/mcts_cpp.<ext>.so      CPython extension over the C ABI (reference module name/location,
+                               setup.py:36-65 of the reference: `from src import mcts_cpp`)
+    src/env_cpp.<ext>.so       CPython extension with the host-side Env objects
+
+Device code is compiled with -ffp-contract=off: the search must round exactly like the
+reference (explicit fmaf() marks the three contractions its compiled form contains).
+"""
+import os
+import subprocess
+import sys
+import sysconfig
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+INC = os.path.join(ROOT, "include")
+LIB = os.path.join(HERE, "lib")
+SRC = os.path.join(HERE, "src")
+EXT = sysconfig.get_config_var("EXT_SUFFIX")
+ARCH = os.environ.get("AZ_OFFLOAD_ARCH", "gfx950")
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def build_engine(force=False):
+    os.makedirs(LIB, exist_ok=True)
+    out = os.path.join(LIB, "libaz_mcts.so")
+    srcs = [os.path.join(CSRC, f) for f in ("kernels.hip", "engine.hip")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("kernels.h", "tree_layout.h", "host_rng.h")] + \
+        [os.path.join(INC, "az_mcts.h")]
+    if force or _stale(out, deps):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        _run([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+              "-shared", "-I", INC, "-I", CSRC, *srcs, "-o", out])
+    return out
+
+
+def build_module(name, source, link_engine, force=False):
+    import pybind11
+    os.makedirs(SRC, exist_ok=True)
+    out = os.path.join(SRC, name + EXT)
+    src = os.path.join(CSRC, source)
+    if force or _stale(out, [src, os.path.join(INC, "az_mcts.h")]):
+        cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden",
+               "-I", INC, "-I", pybind11.get_include(), "-I", sysconfig.get_paths()["include"],
+               src, "-o", out]
+        if link_engine:
+            cmd += ["-L", LIB, "-laz_mcts", "-Wl,-rpath,$ORIGIN/../lib"]
+        _run(cmd)
+    return out
+
+
+def build_all(force=False):
+    build_engine(force)
+    build_module("mcts_cpp", "mcts_module.cpp", True, force)
+    build_module("env_cpp", "env_module.cpp", False, force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

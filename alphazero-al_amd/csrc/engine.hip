@@ -1,0 +1,747 @@
+// engine.hip - host side of libaz_mcts.so: owns the HBM arenas, snapshots the live config,
+// feeds the reference-compatible host generator, and implements the C ABI of
+// include/az_mcts.h on top of the kernels in kernels.hip.
+//
+// Host entry points are synchronous and use the NULL stream (they mirror the reference's
+// blocking pybind calls, mcts_bindings.cpp:126-131 etc.).  Device entry points only enqueue
+// work on the caller's stream.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "az_mcts.h"
+#include "host_rng.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct AzError : std::runtime_error {
+    int code;
+    AzError(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+void hip_check(hipError_t e, const char *what)
+{
+    if (e != hipSuccess)
+        throw AzError(AZ_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_OK(x) hip_check((x), #x)
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    void ensure(size_t count, bool zero = false)
+    {
+        if (count <= n) return;
+        if (p) HIP_OK(hipFree(p));
+        p = nullptr;
+        HIP_OK(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
+        n = count;
+        if (zero) HIP_OK(hipMemset(p, 0, count * sizeof(T)));
+    }
+};
+
+struct LeafStore {
+    DevBuf<int32_t> slot, turn, path_len, path, sym;
+    DevBuf<uint64_t> bb0, bb1;
+    DevBuf<uint8_t> flags;
+    void ensure(size_t leaves)
+    {
+        const bool grow = leaves > slot.n;
+        slot.ensure(leaves); turn.ensure(leaves); bb0.ensure(leaves); bb1.ensure(leaves);
+        sym.ensure(leaves, true);
+        if (grow) {
+            flags.ensure(leaves, true);
+            path_len.ensure(leaves, true);   // 0 == "no descent recorded" (current_leaf_idx == -1)
+            path.ensure(leaves * az::C4_MAX_PATH);
+        }
+    }
+    az::LeafBuf view()
+    {
+        az::LeafBuf v;
+        v.slot = slot.p; v.bb0 = bb0.p; v.bb1 = bb1.p; v.turn = turn.p; v.flags = flags.p;
+        v.path_len = path_len.p; v.path = path.p; v.sym = sym.p;
+        return v;
+    }
+};
+
+constexpr int A = az::C4_ACTIONS;
+constexpr int CELLS = az::C4_CELLS;
+constexpr int STATS = az::C4_STATS;
+constexpr int64_t kInitialSlots = 4096;
+constexpr int kCpuctTab = 1 << 16;
+
+}  // namespace
+
+struct az_mcts {
+    int game = AZ_GAME_CONNECT4;
+    int B = 0;
+    int device = 0;
+    az_search_config cfg;
+
+    // trees
+    DevBuf<az::HotRec> hot;
+    DevBuf<az::ColdRec> cold;
+    DevBuf<int32_t> root, used;
+    int64_t S = 0;
+    int64_t used_bound = 1;   // host-side upper bound of max(used[])
+
+    // roots of the current call
+    DevBuf<uint64_t> r_bb0, r_bb1;
+    DevBuf<int32_t> r_turn, r_last;
+
+    LeafStore vl_leaf, plain_leaf;
+    int vl_stride = 0;        // K of the last VL selection (flat = tree*K + k)
+    bool last_select_vl = false;
+
+    // c_puct table
+    DevBuf<float> tab;
+    float tab_c_init = NAN, tab_c_base = NAN;
+
+    DevBuf<unsigned long long> counters;
+    DevBuf<int> err;
+    DevBuf<uint64_t> call_ctr;
+    int64_t select_launches = 0, backprop_launches = 0;
+
+    // IO buffers of the host entry points
+    DevBuf<int8_t> io_boards_in, io_boards_out;
+    DevBuf<int32_t> io_turns_in, io_sym_in, io_actions, io_noise_req, io_counts;
+    DevBuf<uint8_t> io_mask_out, io_is_term, io_reset_mask;
+    DevBuf<float> io_policy, io_d, io_p1, io_p2, io_ml, io_noise, io_stats;
+
+    // host generator and what it needs to know between search and backprop
+    az::HostRng rng;
+    uint64_t dev_seed = 0x5eed;
+    std::vector<uint8_t> stash_flags_vl, stash_flags_plain;
+    std::vector<uint8_t> stash_root_nv;   // open columns of each root (valid moves of an unexpanded root)
+    std::vector<uint8_t> pending_reset;
+    bool any_pending_reset = false;
+
+    az::TreeArena arena()
+    {
+        az::TreeArena a;
+        a.hot = hot.p; a.cold = cold.p; a.root = root.p; a.used = used.p; a.S = S; a.B = B;
+        return a;
+    }
+    az::RootState roots()
+    {
+        az::RootState r;
+        r.bb0 = r_bb0.p; r.bb1 = r_bb1.p; r.turn = r_turn.p; r.last = r_last.p;
+        return r;
+    }
+
+    void ensure_table()
+    {
+        // logf through the host libm, float arithmetic in the reference's order (MCTS.h:213-214)
+        if (tab.p && cfg.c_init == tab_c_init && cfg.c_base == tab_c_base) return;
+        std::vector<float> h(kCpuctTab);
+        const float c_init = cfg.c_init, c_base = cfg.c_base;
+        for (int n = 0; n < kCpuctTab; ++n) {
+            const float parent_n = static_cast<float>(n);
+            h[n] = c_init + std::log((parent_n + c_base + 1.0f) / c_base);
+        }
+        tab.ensure(kCpuctTab);
+        HIP_OK(hipMemcpy(tab.p, h.data(), sizeof(float) * kCpuctTab, hipMemcpyHostToDevice));
+        tab_c_init = c_init; tab_c_base = c_base;
+    }
+
+    az::SearchParams params()
+    {
+        ensure_table();
+        az::SearchParams p;
+        p.c_init = cfg.c_init; p.c_base = cfg.c_base; p.noise_eps = cfg.noise_epsilon;
+        p.fpu_reduction = cfg.fpu_reduction; p.mlh_slope = cfg.mlh_slope; p.mlh_cap = cfg.mlh_cap;
+        p.value_decay = cfg.value_decay; p.alpha = cfg.dirichlet_alpha;
+        p.vl_count = cfg.vl_count; p.use_symmetry = cfg.use_symmetry ? 1 : 0;
+        p.cpuct_tab = tab.p; p.tab_n = kCpuctTab;
+        p.seed = dev_seed; p.call_ptr = call_ctr.p;
+        return p;
+    }
+
+    void flush_resets(hipStream_t s)
+    {
+        if (!any_pending_reset) return;
+        io_reset_mask.ensure(B);
+        HIP_OK(hipMemcpy(io_reset_mask.p, pending_reset.data(), B, hipMemcpyHostToDevice));
+        az::launch_reset_masked(arena(), io_reset_mask.p, s);
+        std::fill(pending_reset.begin(), pending_reset.end(), 0);
+        any_pending_reset = false;
+    }
+
+    int64_t true_max_used()
+    {
+        std::vector<int32_t> h(B);
+        HIP_OK(hipMemcpy(h.data(), used.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
+        return *std::max_element(h.begin(), h.end());
+    }
+
+    void grow(int64_t new_S)
+    {
+        HIP_OK(hipDeviceSynchronize());
+        const int64_t keep = std::min<int64_t>(S, true_max_used());
+        DevBuf<az::HotRec> nh;
+        DevBuf<az::ColdRec> nc;
+        nh.ensure(static_cast<size_t>(B) * new_S);
+        nc.ensure(static_cast<size_t>(B) * new_S);
+        HIP_OK(hipMemcpy2D(nh.p, new_S * sizeof(az::HotRec), hot.p, S * sizeof(az::HotRec),
+                           keep * sizeof(az::HotRec), B, hipMemcpyDeviceToDevice));
+        HIP_OK(hipMemcpy2D(nc.p, new_S * sizeof(az::ColdRec), cold.p, S * sizeof(az::ColdRec),
+                           keep * sizeof(az::ColdRec), B, hipMemcpyDeviceToDevice));
+        std::swap(hot.p, nh.p); std::swap(hot.n, nh.n);
+        std::swap(cold.p, nc.p); std::swap(cold.n, nc.n);
+        S = new_S;
+    }
+
+    // room for `extra` more records in every tree (an expansion appends at most A records)
+    void ensure_room(int64_t extra)
+    {
+        if (used_bound + extra > S) {
+            used_bound = true_max_used();
+            if (used_bound + extra > S) grow(std::max<int64_t>(2 * S, used_bound + extra));
+        }
+        used_bound += extra;
+    }
+
+    void check_device_error()
+    {
+        int e = 0;
+        HIP_OK(hipMemcpy(&e, err.p, sizeof(int), hipMemcpyDeviceToHost));
+        if (e) {
+            HIP_OK(hipMemset(err.p, 0, sizeof(int)));
+            throw AzError(AZ_ERR_CAPACITY, "tree arena overflow on device");
+        }
+    }
+};
+
+namespace {
+
+az_mcts *create_engine(int game, int n_envs, int device)
+{
+    if (game != AZ_GAME_CONNECT4) throw AzError(AZ_ERR_ARG, "unknown game id");
+    if (n_envs <= 0) throw AzError(AZ_ERR_ARG, "n_envs must be positive");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        throw AzError(AZ_ERR_DEVICE, "no HIP device available: the search engine runs on the GPU only");
+    if (device >= 0) HIP_OK(hipSetDevice(device));
+    auto *m = new az_mcts();
+    try {
+        HIP_OK(hipGetDevice(&m->device));
+        m->B = n_envs;
+        m->cfg.c_init = 1.25f; m->cfg.c_base = 19652.0f; m->cfg.dirichlet_alpha = 0.3f;
+        m->cfg.noise_epsilon = 0.25f; m->cfg.fpu_reduction = 0.4f; m->cfg.mlh_slope = 0.0f;
+        m->cfg.mlh_cap = 0.2f; m->cfg.score_utility_factor = 0.0f; m->cfg.score_scale = 8.0f;
+        m->cfg.value_decay = 1.0f; m->cfg.use_symmetry = 1; m->cfg.vl_count = 1;
+        m->S = kInitialSlots;
+        m->hot.ensure(static_cast<size_t>(n_envs) * m->S);
+        m->cold.ensure(static_cast<size_t>(n_envs) * m->S);
+        m->root.ensure(n_envs); m->used.ensure(n_envs);
+        m->r_bb0.ensure(n_envs, true); m->r_bb1.ensure(n_envs, true);
+        m->r_turn.ensure(n_envs, true); m->r_last.ensure(n_envs, true);
+        m->counters.ensure(az::CNT_N, true);
+        m->err.ensure(1, true);
+        m->call_ctr.ensure(1, true);
+        m->plain_leaf.ensure(n_envs);
+        m->pending_reset.assign(n_envs, 0);
+        m->stash_root_nv.assign(n_envs, 0);
+        az::launch_init_trees(m->arena(), nullptr);
+        HIP_OK(hipDeviceSynchronize());
+    } catch (...) {
+        delete m;
+        throw;
+    }
+    return m;
+}
+
+template <class F>
+int guarded(F &&f)
+{
+    try {
+        f();
+        return AZ_OK;
+    } catch (const AzError &e) {
+        g_last_error = e.what();
+        return e.code;
+    } catch (const std::exception &e) {
+        g_last_error = e.what();
+        return AZ_ERR_DEVICE;
+    }
+}
+
+void require(bool ok, const std::string &msg)
+{
+    if (!ok) throw AzError(AZ_ERR_ARG, msg);
+}
+
+// Shared body of search_batch / search_batch_vl (BatchedMCTS.h:119-171, 227-286)
+void host_search(az_mcts *m, int K, bool vl, const int8_t *boards, const int32_t *turns,
+                 int8_t *out_boards, float *out_d, float *out_p1w, float *out_p2w,
+                 uint8_t *out_is_term, int32_t *out_turns, int32_t *out_sym, uint8_t *out_mask)
+{
+    HIP_OK(hipSetDevice(m->device));
+    const int B = m->B;
+    const size_t total = static_cast<size_t>(B) * K;
+    hipStream_t s = nullptr;
+    m->flush_resets(s);
+
+    m->io_boards_in.ensure(static_cast<size_t>(B) * CELLS);
+    m->io_turns_in.ensure(B);
+    HIP_OK(hipMemcpy(m->io_boards_in.p, boards, static_cast<size_t>(B) * CELLS, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(m->io_turns_in.p, turns, sizeof(int32_t) * B, hipMemcpyHostToDevice));
+    az::launch_import(m->io_boards_in.p, m->io_turns_in.p, m->roots(), B, s);
+
+    LeafStore &ls = vl ? m->vl_leaf : m->plain_leaf;
+    ls.ensure(total);
+    if (vl) m->vl_stride = K;
+    m->last_select_vl = vl;
+    const az::SearchParams p = m->params();
+    az::launch_select(m->arena(), m->roots(), ls.view(), p, K, vl, m->counters.p, s);
+    ++m->select_launches;
+
+    std::vector<uint8_t> flags(total);
+    HIP_OK(hipMemcpy(flags.data(), ls.flags.p, total, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(out_turns, ls.turn.p, sizeof(int32_t) * total, hipMemcpyDeviceToHost));
+
+    // symmetry ids in env order, one draw per NON-terminal leaf (BatchedMCTS.h:148-158,261-271)
+    std::vector<int32_t> sym(total, 0);
+    const bool use_sym = m->cfg.use_symmetry != 0;
+    for (size_t f = 0; f < total; ++f) {
+        const bool term = (flags[f] & az::LEAF_TERMINAL) != 0;
+        const int code = (flags[f] >> az::LEAF_RESULT_SHIFT) & 3;
+        out_is_term[f] = term ? 1 : 0;
+        out_d[f] = (term && code == 0) ? 1.0f : 0.0f;
+        out_p1w[f] = (term && code == 1) ? 1.0f : 0.0f;
+        out_p2w[f] = (term && code == 2) ? 1.0f : 0.0f;
+        if (!term && use_sym) sym[f] = m->rng.uniform_int(1);
+    }
+    if (out_sym) std::memcpy(out_sym, sym.data(), sizeof(int32_t) * total);
+    HIP_OK(hipMemcpy(ls.sym.p, sym.data(), sizeof(int32_t) * total, hipMemcpyHostToDevice));
+
+    m->io_boards_out.ensure(total * CELLS);
+    m->io_mask_out.ensure(total * A);
+    az::launch_export(ls.view(), p, static_cast<int>(total), false, m->io_boards_out.p,
+                      m->io_mask_out.p, nullptr, s);
+    HIP_OK(hipMemcpy(out_boards, m->io_boards_out.p, total * CELLS, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(out_mask, m->io_mask_out.p, total * A, hipMemcpyDeviceToHost));
+
+    // what the host generator needs at expansion time
+    (vl ? m->stash_flags_vl : m->stash_flags_plain) = std::move(flags);
+    for (int i = 0; i < B; ++i) {
+        int nv = 0;
+        for (int c = 0; c < az::C4_COLS; ++c) nv += boards[static_cast<size_t>(i) * CELLS + c] == 0;
+        m->stash_root_nv[i] = static_cast<uint8_t>(nv);
+    }
+}
+
+// Shared body of backprop_batch / backprop_batch_vl (BatchedMCTS.h:176-199, 296-332)
+void host_backprop(az_mcts *m, int K, bool vl, const float *policy, const float *d, const float *p1w,
+                   const float *p2w, const float *ml, const uint8_t *is_term, const int32_t *sym_ids)
+{
+    HIP_OK(hipSetDevice(m->device));
+    const int B = m->B;
+    hipStream_t s = nullptr;
+    m->flush_resets(s);
+    LeafStore &ls = vl ? m->vl_leaf : m->plain_leaf;
+    if (vl) require(m->vl_stride == K, "backprop_batch_vl: K differs from the preceding search_batch_vl");
+    const size_t total = static_cast<size_t>(B) * K;
+    ls.ensure(total);
+    m->ensure_room(static_cast<int64_t>(K) * A);
+
+    // Dirichlet noise for roots expanded by this call, drawn in env order (MCTS.h:347-363)
+    m->io_noise.ensure(static_cast<size_t>(B) * A, true);
+    const std::vector<uint8_t> &fl = vl ? m->stash_flags_vl : m->stash_flags_plain;
+    if (m->cfg.dirichlet_alpha > 0.0f && fl.size() == total) {
+        std::vector<float> noise(static_cast<size_t>(B) * A, 0.0f);
+        bool any = false;
+        for (int i = 0; i < B; ++i)
+            for (int k = 0; k < K; ++k) {
+                const size_t f = static_cast<size_t>(i) * K + k;
+                if ((fl[f] & az::LEAF_ROOT_UNEXPANDED) && !is_term[f]) {
+                    m->rng.dirichlet(m->cfg.dirichlet_alpha, &noise[static_cast<size_t>(i) * A],
+                                     m->stash_root_nv[i]);
+                    any = true;
+                    break;   // later k find the root expanded (MCTS.h:601-607)
+                }
+            }
+        if (any)
+            HIP_OK(hipMemcpy(m->io_noise.p, noise.data(), sizeof(float) * noise.size(), hipMemcpyHostToDevice));
+    }
+    (vl ? m->stash_flags_vl : m->stash_flags_plain).clear();
+
+    m->io_policy.ensure(total * A); m->io_d.ensure(total); m->io_p1.ensure(total);
+    m->io_p2.ensure(total); m->io_ml.ensure(total); m->io_is_term.ensure(total);
+    HIP_OK(hipMemcpy(m->io_policy.p, policy, sizeof(float) * total * A, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(m->io_d.p, d, sizeof(float) * total, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(m->io_p1.p, p1w, sizeof(float) * total, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(m->io_p2.p, p2w, sizeof(float) * total, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(m->io_ml.p, ml, sizeof(float) * total, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(m->io_is_term.p, is_term, total, hipMemcpyHostToDevice));
+    az::EvalIn in{};
+    in.policy = m->io_policy.p; in.d = m->io_d.p; in.p1w = m->io_p1.p; in.p2w = m->io_p2.p;
+    in.is_term = m->io_is_term.p; in.moves_left = m->io_ml.p; in.wdl_rel = nullptr;
+    in.root_noise = m->io_noise.p;
+    in.sym = nullptr;   // plain: the ids stored by search_batch (pending_sym_ids_, BatchedMCTS.h:152)
+    if (vl) {
+        m->io_sym_in.ensure(total);
+        HIP_OK(hipMemcpy(m->io_sym_in.p, sym_ids, sizeof(int32_t) * total, hipMemcpyHostToDevice));
+        in.sym = m->io_sym_in.p;
+    }
+    az::launch_backprop(m->arena(), ls.view(), m->params(), K, vl, false, in, m->counters.p, m->err.p, s);
+    ++m->backprop_launches;
+    HIP_OK(hipStreamSynchronize(s));
+    m->check_device_error();
+}
+
+}  // namespace
+
+// ====================================================================== C ABI
+
+extern "C" {
+
+const char *az_last_error(void) { return g_last_error.c_str(); }
+
+int az_game_action_size(int game) { return game == AZ_GAME_CONNECT4 ? az::C4_ACTIONS : -1; }
+int az_game_board_size(int game) { return game == AZ_GAME_CONNECT4 ? az::C4_CELLS : -1; }
+int az_game_board_rows(int game) { return game == AZ_GAME_CONNECT4 ? az::C4_ROWS : -1; }
+int az_game_board_cols(int game) { return game == AZ_GAME_CONNECT4 ? az::C4_COLS : -1; }
+
+int az_mcts_create(int game, int n_envs, int device, az_mcts **out)
+{
+    return guarded([&] {
+        require(out != nullptr, "out is null");
+        *out = create_engine(game, n_envs, device);
+    });
+}
+
+void az_mcts_destroy(az_mcts *m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    (void)hipDeviceSynchronize();
+    delete m;
+}
+
+az_search_config *az_mcts_config(az_mcts *m) { return &m->cfg; }
+int az_mcts_num_envs(const az_mcts *m) { return m->B; }
+
+int az_mcts_set_seed(az_mcts *m, int seed)
+{
+    return guarded([&] {
+        if (seed < 0) {                       // BatchedMCTS.h:73-76
+            m->rng.seed_random();
+            m->dev_seed = (static_cast<uint64_t>(m->rng.next()) << 32) | m->rng.next();
+        } else {                              // thread 0: seed + 0*10007 (BatchedMCTS.h:79-81)
+            m->rng.seed(static_cast<uint32_t>(seed));
+            m->dev_seed = static_cast<uint64_t>(static_cast<uint32_t>(seed)) * 0x9E3779B97F4A7C15ull + 1;
+        }
+        HIP_OK(hipSetDevice(m->device));
+        HIP_OK(hipMemset(m->call_ctr.p, 0, sizeof(uint64_t)));
+    });
+}
+
+int az_mcts_reset_env(az_mcts *m, int env)
+{
+    if (env >= 0 && env < m->B) {             // silently ignores out-of-range (BatchedMCTS.h:95)
+        m->pending_reset[env] = 1;
+        m->any_pending_reset = true;
+    }
+    return AZ_OK;
+}
+
+int az_mcts_prune_roots(az_mcts *m, const int32_t *actions, int64_t n)
+{
+    return guarded([&] {
+        require(n == m->B, "prune_roots: actions size (" + std::to_string(n) + ") must match n_envs (" +
+                               std::to_string(m->B) + ")");
+        HIP_OK(hipSetDevice(m->device));
+        hipStream_t s = nullptr;
+        m->flush_resets(s);
+        const int B = m->B;
+        m->io_actions.ensure(B); m->io_noise_req.ensure(B, true);
+        HIP_OK(hipMemcpy(m->io_actions.p, actions, sizeof(int32_t) * B, hipMemcpyHostToDevice));
+        const az::SearchParams p = m->params();
+        az::launch_prune(m->arena(), p, m->io_actions.p, m->io_noise_req.p, false, s);
+        if (m->cfg.dirichlet_alpha > 0.0f) {  // apply_root_noise, env order (MCTS.h:113-132)
+            std::vector<int32_t> req(B);
+            HIP_OK(hipMemcpy(req.data(), m->io_noise_req.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
+            std::vector<float> noise(static_cast<size_t>(B) * A, 0.0f);
+            bool any = false;
+            for (int i = 0; i < B; ++i)
+                if (req[i] > 0) {
+                    m->rng.dirichlet(m->cfg.dirichlet_alpha, &noise[static_cast<size_t>(i) * A], req[i]);
+                    any = true;
+                }
+            if (any) {
+                m->io_noise.ensure(static_cast<size_t>(B) * A);
+                HIP_OK(hipMemcpy(m->io_noise.p, noise.data(), sizeof(float) * noise.size(), hipMemcpyHostToDevice));
+                az::launch_apply_noise(m->arena(), m->io_noise_req.p, m->io_noise.p, s);
+            }
+        }
+        HIP_OK(hipStreamSynchronize(s));
+    });
+}
+
+int az_mcts_search_batch(az_mcts *m, const int8_t *boards, const int32_t *turns, int64_t n,
+                         int8_t *out_boards, float *out_term_d, float *out_term_p1w,
+                         float *out_term_p2w, uint8_t *out_is_term, int32_t *out_turns,
+                         uint8_t *out_valid_mask)
+{
+    return guarded([&] {
+        require(n == m->B, "search_batch: input_boards batch size (" + std::to_string(n) +
+                               ") must match n_envs (" + std::to_string(m->B) + ")");
+        host_search(m, 1, false, boards, turns, out_boards, out_term_d, out_term_p1w, out_term_p2w,
+                    out_is_term, out_turns, nullptr, out_valid_mask);
+    });
+}
+
+int az_mcts_backprop_batch(az_mcts *m, const float *policy, const float *d, const float *p1w,
+                           const float *p2w, const float *moves_left, const uint8_t *is_term,
+                           int64_t n)
+{
+    return guarded([&] {
+        require(n == m->B, "backprop_batch: policy_logits batch size (" + std::to_string(n) +
+                               ") must match n_envs (" + std::to_string(m->B) + ")");
+        host_backprop(m, 1, false, policy, d, p1w, p2w, moves_left, is_term, nullptr);
+    });
+}
+
+int az_mcts_remove_all_vl(az_mcts *m, int K)
+{
+    return guarded([&] {
+        HIP_OK(hipSetDevice(m->device));
+        if (m->vl_stride <= 0 || K <= 0) return;
+        const int kk = std::min(K, m->vl_stride);          // safe_K, MCTS.h:563
+        az::launch_remove_vl(m->arena(), m->vl_leaf.view(), m->params(), kk, m->vl_stride, nullptr);
+        HIP_OK(hipStreamSynchronize(nullptr));
+    });
+}
+
+int az_mcts_search_batch_vl(az_mcts *m, int K, const int8_t *boards, const int32_t *turns,
+                            int64_t n, int8_t *out_boards, float *out_term_d,
+                            float *out_term_p1w, float *out_term_p2w, uint8_t *out_is_term,
+                            int32_t *out_turns, int32_t *out_sym_ids, uint8_t *out_valid_mask)
+{
+    return guarded([&] {
+        require(n == m->B, "search_batch_vl: input batch (" + std::to_string(n) + ") != n_envs (" +
+                               std::to_string(m->B) + ")");
+        require(K >= 1, "search_batch_vl: K must be >= 1");
+        host_search(m, K, true, boards, turns, out_boards, out_term_d, out_term_p1w, out_term_p2w,
+                    out_is_term, out_turns, out_sym_ids, out_valid_mask);
+    });
+}
+
+int az_mcts_backprop_batch_vl(az_mcts *m, int K, const float *policy, const float *d,
+                              const float *p1w, const float *p2w, const float *moves_left,
+                              const uint8_t *is_term, const int32_t *sym_ids, int64_t total)
+{
+    return guarded([&] {
+        require(K >= 1, "backprop_batch_vl: K must be >= 1");
+        require(total == static_cast<int64_t>(m->B) * K,
+                "backprop_batch_vl: policy batch (" + std::to_string(total) + ") != N*K (" +
+                    std::to_string(static_cast<int64_t>(m->B) * K) + ")");
+        host_backprop(m, K, true, policy, d, p1w, p2w, moves_left, is_term, sym_ids);
+    });
+}
+
+int az_mcts_search_rollout(az_mcts *, const int8_t *, const int32_t *, int64_t, int)
+{
+    g_last_error = "search with RolloutEvaluator is not implemented on the device yet";
+    return AZ_ERR_STATE;
+}
+
+int az_mcts_get_all_counts(az_mcts *m, int32_t *out)
+{
+    return guarded([&] {
+        HIP_OK(hipSetDevice(m->device));
+        m->flush_resets(nullptr);
+        m->io_counts.ensure(static_cast<size_t>(m->B) * A);
+        az::launch_counts(m->arena(), m->io_counts.p, nullptr);
+        HIP_OK(hipMemcpy(out, m->io_counts.p, sizeof(int32_t) * m->B * A, hipMemcpyDeviceToHost));
+    });
+}
+
+int az_mcts_get_all_root_stats(az_mcts *m, float *out)
+{
+    return guarded([&] {
+        HIP_OK(hipSetDevice(m->device));
+        m->flush_resets(nullptr);
+        m->io_stats.ensure(static_cast<size_t>(m->B) * STATS);
+        az::launch_root_stats(m->arena(), m->io_stats.p, nullptr);
+        HIP_OK(hipMemcpy(out, m->io_stats.p, sizeof(float) * m->B * STATS, hipMemcpyDeviceToHost));
+    });
+}
+
+// ---------------------------------------------------------------- device entry points
+
+int az_mcts_dev_prepare(az_mcts *m, int K, int64_t sims_per_tree)
+{
+    return guarded([&] {
+        require(K >= 1, "dev_prepare: K must be >= 1");
+        HIP_OK(hipSetDevice(m->device));
+        m->flush_resets(nullptr);
+        m->vl_leaf.ensure(static_cast<size_t>(m->B) * K);
+        m->plain_leaf.ensure(m->B);
+        m->ensure_table();
+        m->ensure_room(sims_per_tree * A);
+        HIP_OK(hipDeviceSynchronize());
+    });
+}
+
+int az_mcts_dev_set_roots(az_mcts *m, const uint64_t *bb_p1, const uint64_t *bb_p2,
+                          const int32_t *turns, void *stream)
+{
+    return guarded([&] {
+        az::launch_set_roots(bb_p1, bb_p2, turns, m->roots(), m->B, static_cast<hipStream_t>(stream));
+    });
+}
+
+int az_mcts_dev_import_roots(az_mcts *m, const int8_t *boards, const int32_t *turns, void *stream)
+{
+    return guarded([&] {
+        az::launch_import(boards, turns, m->roots(), m->B, static_cast<hipStream_t>(stream));
+    });
+}
+
+int az_mcts_dev_select(az_mcts *m, int K, int vl, float *features, uint8_t *valid_mask, void *stream)
+{
+    return guarded([&] {
+        require(K >= 1 && (vl || K == 1), "dev_select: K must be 1 without virtual loss");
+        LeafStore &ls = vl ? m->vl_leaf : m->plain_leaf;
+        const size_t total = static_cast<size_t>(m->B) * K;
+        require(ls.slot.n >= total && m->tab.p, "dev_select: call az_mcts_dev_prepare first");
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        if (vl) m->vl_stride = K;
+        m->last_select_vl = vl != 0;
+        const az::SearchParams p = m->params();
+        az::launch_select(m->arena(), m->roots(), ls.view(), p, K, vl != 0, m->counters.p, s);
+        az::launch_export(ls.view(), p, static_cast<int>(total), true, nullptr, valid_mask, features, s);
+        az::launch_bump_call(m->call_ctr.p, s);
+        ++m->select_launches;
+    });
+}
+
+int az_mcts_dev_backprop(az_mcts *m, int K, int vl, const float *probs, const float *wdl_rel,
+                         const float *moves_left, void *stream)
+{
+    return guarded([&] {
+        require(K >= 1 && (vl || K == 1), "dev_backprop: K must be 1 without virtual loss");
+        if (vl) require(m->vl_stride == K, "dev_backprop: K differs from the preceding dev_select");
+        LeafStore &ls = vl ? m->vl_leaf : m->plain_leaf;
+        az::EvalIn in{};
+        in.policy = probs; in.wdl_rel = wdl_rel; in.moves_left = moves_left;
+        in.root_noise = nullptr; in.sym = nullptr;
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        az::launch_backprop(m->arena(), ls.view(), m->params(), K, vl != 0, true, in, m->counters.p,
+                            m->err.p, s);
+        az::launch_bump_call(m->call_ctr.p, s);
+        ++m->backprop_launches;
+    });
+}
+
+int az_mcts_dev_leaves(az_mcts *m, int K, uint64_t *bb_p1, uint64_t *bb_p2, int32_t *turns,
+                       uint8_t *flags, void *stream)
+{
+    return guarded([&] {
+        LeafStore &ls = m->last_select_vl ? m->vl_leaf : m->plain_leaf;
+        const size_t total = static_cast<size_t>(m->B) * K;
+        require(ls.slot.n >= total, "dev_leaves: no selection of that width");
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        if (bb_p1) HIP_OK(hipMemcpyAsync(bb_p1, ls.bb0.p, 8 * total, hipMemcpyDeviceToDevice, s));
+        if (bb_p2) HIP_OK(hipMemcpyAsync(bb_p2, ls.bb1.p, 8 * total, hipMemcpyDeviceToDevice, s));
+        if (turns) HIP_OK(hipMemcpyAsync(turns, ls.turn.p, 4 * total, hipMemcpyDeviceToDevice, s));
+        if (flags) HIP_OK(hipMemcpyAsync(flags, ls.flags.p, total, hipMemcpyDeviceToDevice, s));
+    });
+}
+
+int az_mcts_dev_counts(az_mcts *m, int32_t *counts, void *stream)
+{
+    return guarded([&] { az::launch_counts(m->arena(), counts, static_cast<hipStream_t>(stream)); });
+}
+
+int az_mcts_dev_root_stats(az_mcts *m, float *stats, void *stream)
+{
+    return guarded([&] { az::launch_root_stats(m->arena(), stats, static_cast<hipStream_t>(stream)); });
+}
+
+int az_mcts_dev_prune_roots(az_mcts *m, const int32_t *actions, void *stream)
+{
+    return guarded([&] {
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        az::launch_prune(m->arena(), m->params(), actions, nullptr, true, s);
+        az::launch_bump_call(m->call_ctr.p, s);
+    });
+}
+
+int az_mcts_dev_reset_masked(az_mcts *m, const uint8_t *mask, void *stream)
+{
+    return guarded([&] { az::launch_reset_masked(m->arena(), mask, static_cast<hipStream_t>(stream)); });
+}
+
+// ---------------------------------------------------------------- capacity / instrumentation
+
+int az_mcts_reserve(az_mcts *m, int64_t slots_per_tree)
+{
+    return guarded([&] {
+        HIP_OK(hipSetDevice(m->device));
+        if (slots_per_tree > m->S) m->grow(slots_per_tree);
+    });
+}
+
+int64_t az_mcts_capacity(const az_mcts *m) { return m->S; }
+
+int az_mcts_max_used(az_mcts *m, int64_t *out)
+{
+    return guarded([&] {
+        HIP_OK(hipSetDevice(m->device));
+        m->flush_resets(nullptr);
+        HIP_OK(hipDeviceSynchronize());
+        *out = m->true_max_used();
+        m->used_bound = *out;
+    });
+}
+
+int az_mcts_counters(az_mcts *m, int64_t out[AZ_NUM_COUNTERS])
+{
+    return guarded([&] {
+        HIP_OK(hipSetDevice(m->device));
+        unsigned long long h[az::CNT_N];
+        HIP_OK(hipDeviceSynchronize());
+        HIP_OK(hipMemcpy(h, m->counters.p, sizeof h, hipMemcpyDeviceToHost));
+        for (int i = 0; i < az::CNT_N; ++i) out[i] = static_cast<int64_t>(h[i]);
+        out[az::CNT_SELECT_LAUNCHES] = m->select_launches;
+        out[az::CNT_BACKPROP_LAUNCHES] = m->backprop_launches;
+        m->check_device_error();
+    });
+}
+
+int az_mcts_counters_reset(az_mcts *m)
+{
+    return guarded([&] {
+        HIP_OK(hipSetDevice(m->device));
+        HIP_OK(hipDeviceSynchronize());
+        HIP_OK(hipMemset(m->counters.p, 0, sizeof(unsigned long long) * az::CNT_N));
+        m->select_launches = m->backprop_launches = 0;
+    });
+}
+
+int az_rng_gamma_selftest(uint32_t seed, float alpha, int count, float *out)
+{
+    az::HostRng r;
+    r.seed(seed);
+    r.gamma_fill(alpha, out, count);
+    return AZ_OK;
+}
+
+}  // extern "C"

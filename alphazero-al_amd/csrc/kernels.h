@@ -1,0 +1,97 @@
+// kernels.h - launch interface between the host engine (engine.hip) and the gfx950 kernels
+// (kernels.hip).  Everything here is plain data: device pointers and sizes.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "tree_layout.h"
+
+namespace az {
+
+// Search parameters of one launch: a by-value snapshot of the live az_search_config
+// (MCTSNode.h:47-61) plus what the device needs besides.
+struct SearchParams {
+    float c_init, c_base, noise_eps, fpu_reduction, mlh_slope, mlh_cap, value_decay, alpha;
+    int   vl_count;
+    int   use_symmetry;
+    // c_puct(parent_n) = c_init + logf((parent_n + c_base + 1)/c_base) for parent_n < tab_n,
+    // tabulated by the HOST libm so that the device takes the same branch the reference's
+    // logf takes (MCTS.h:213-214).
+    const float *cpuct_tab;
+    int   tab_n;
+    // device generator key (used by the dev_* entry points only).  `call_ptr` points at a
+    // counter in HBM that a one-thread kernel bumps after every use, so that a captured
+    // hipGraph draws fresh numbers on every replay.
+    uint64_t seed;
+    const uint64_t *call_ptr;
+};
+
+struct TreeArena {
+    HotRec  *hot;
+    ColdRec *cold;
+    int32_t *root;   // [B] slot of each tree's root
+    int32_t *used;   // [B] slots in use
+    int64_t  S;      // slots per tree
+    int      B;      // trees
+};
+
+// Root positions of the current call (Connect4: two bitboards + side to move + last mover)
+struct RootState {
+    uint64_t *bb0, *bb1;
+    int32_t  *turn;
+    int32_t  *last;  // index of the last mover (0/1), -1 when the board is empty (Connect4.h:124-128)
+};
+
+// What a descent leaves behind for expansion/backup; flat index = tree*K + k
+struct LeafBuf {
+    int32_t  *slot;      // leaf node
+    uint64_t *bb0, *bb1; // leaf position (unsymmetrised)
+    int32_t  *turn;      // side to move at the leaf
+    uint8_t  *flags;     // LEAF_*
+    int32_t  *path_len;  // nodes on the path, root first (0 = no descent recorded)
+    int32_t  *path;      // [flat*C4_MAX_PATH + depth]
+    int32_t  *sym;       // symmetry id shown to the evaluator
+};
+
+// Evaluator outputs for one backprop launch
+struct EvalIn {
+    const float   *policy;    // [n*K, A] in the frame the evaluator saw
+    // host form (reference signature): absolute WDL and flags supplied by the caller
+    const float   *d, *p1w, *p2w;
+    const uint8_t *is_term;
+    const int32_t *sym;       // VL host form: per leaf; nullptr -> LeafBuf::sym
+    // fused form: relative [draw, win, loss] per leaf, terminal flag from LeafBuf
+    const float   *wdl_rel;
+    const float   *moves_left;
+    // Dirichlet noise for root expansions, [B, A], already normalised (host RNG mode);
+    // nullptr -> device generator
+    const float   *root_noise;
+};
+
+enum : int { CNT_SIMS = 0, CNT_LEVELS, CNT_EXPANSIONS, CNT_TERMINAL, CNT_DUP, CNT_BACKUP,
+             CNT_SELECT_LAUNCHES, CNT_BACKPROP_LAUNCHES, CNT_N };
+
+void launch_import(const int8_t *boards, const int32_t *turns, RootState rs, int B, hipStream_t s);
+void launch_set_roots(const uint64_t *bb0, const uint64_t *bb1, const int32_t *turns, RootState rs,
+                      int B, hipStream_t s);
+void launch_bump_call(uint64_t *call_ctr, hipStream_t s);
+void launch_select(TreeArena ar, RootState rs, LeafBuf lf, SearchParams p, int K, bool vl,
+                   unsigned long long *counters, hipStream_t s);
+void launch_backprop(TreeArena ar, LeafBuf lf, SearchParams p, int K, bool vl, bool fused,
+                     EvalIn in, unsigned long long *counters, int *err, hipStream_t s);
+void launch_remove_vl(TreeArena ar, LeafBuf lf, SearchParams p, int K, int strideK, hipStream_t s);
+// Leaves -> evaluator input.  gen_sym: draw symmetry ids from the device generator (else read
+// LeafBuf::sym).  Any output pointer may be nullptr.
+void launch_export(LeafBuf lf, SearchParams p, int n_leaves, bool gen_sym, int8_t *boards,
+                   uint8_t *valid_mask, float *features, hipStream_t s);
+void launch_prune(TreeArena ar, SearchParams p, const int32_t *actions, int32_t *noise_req,
+                  bool dev_noise, hipStream_t s);
+void launch_apply_noise(TreeArena ar, const int32_t *noise_req, const float *noise, hipStream_t s);
+void launch_reset_masked(TreeArena ar, const uint8_t *mask, hipStream_t s);
+void launch_counts(TreeArena ar, int32_t *counts, hipStream_t s);
+void launch_root_stats(TreeArena ar, float *stats, hipStream_t s);
+void launch_init_trees(TreeArena ar, hipStream_t s);
+
+}  // namespace az

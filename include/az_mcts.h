@@ -1,0 +1,178 @@
+/*
+ * az_mcts.h - C ABI of the MI355X batched self-play search engine (libaz_mcts.so).
+ *
+ * This is the drop-in boundary for the reference's native search layer: every entry point
+ * below replaces one method the reference binds in src/cpp/mcts_bindings.cpp (cited per
+ * function, paths relative to the reference checkout).  Plain pointers and sizes only; no
+ * torch / pybind types.  All trees live in HBM; the library fails (non-zero return,
+ * message in az_last_error()) when no HIP device is usable - there is no CPU fallback.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error (AZ_ERR_*); the reference
+ *     throws std::runtime_error at the same points (mcts_bindings.cpp:76-79,97-100,
+ *     155-165,206-212,278-288,323-327) and the pybind layer re-raises RuntimeError.
+ *   - "host" entry points take host pointers, are synchronous, and mirror the reference
+ *     signature 1:1 (caller-allocated outputs instead of fresh numpy arrays).
+ *   - "dev" entry points take DEVICE pointers and a hipStream_t (as void*), never
+ *     synchronise, and are what the fused self-play loop uses (no host round trip).
+ *   - flat leaf index of simulation k of tree i in a K-wide call is i*K + k
+ *     (BatchedMCTS.h:221,251).
+ */
+#ifndef AZ_MCTS_H
+#define AZ_MCTS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AZ_OK            0
+#define AZ_ERR_ARG       1   /* size / shape / range mismatch (reference: runtime_error) */
+#define AZ_ERR_DEVICE    2   /* HIP error or no device                                   */
+#define AZ_ERR_CAPACITY  3   /* a tree arena overflowed (cannot happen unless growth is disabled) */
+#define AZ_ERR_STATE     4   /* call sequence not supported                              */
+
+#define AZ_GAME_CONNECT4 0
+
+/* Same fields, order and defaults as the reference SearchConfig (MCTSNode.h:47-61),
+ * exposed as a LIVE struct exactly like `BatchedMCTS.config` (mcts_bindings.cpp:55-58):
+ * the engine re-reads it at every call. */
+typedef struct az_search_config {
+    float   c_init;               /* 1.25    */
+    float   c_base;               /* 19652   */
+    float   dirichlet_alpha;      /* 0.3     */
+    float   noise_epsilon;        /* 0.25    */
+    float   fpu_reduction;        /* 0.4     */
+    float   mlh_slope;            /* 0       */
+    float   mlh_cap;              /* 0.2     */
+    float   score_utility_factor; /* 0       */
+    float   score_scale;          /* 8       */
+    float   value_decay;          /* 1       */
+    uint8_t use_symmetry;         /* true    */
+    int32_t vl_count;             /* 1       */
+} az_search_config;
+
+typedef struct az_mcts az_mcts;
+
+/* thread-local message of the last failing call */
+const char *az_last_error(void);
+
+/* static game geometry: BatchedMCTS_<G>.action_size / board_size (mcts_bindings.cpp:359-369) */
+int az_game_action_size(int game);
+int az_game_board_size(int game);
+int az_game_board_rows(int game);
+int az_game_board_cols(int game);
+
+/* ---- lifetime ------------------------------------------------------------------------ */
+
+/* BatchedMCTS(int n_envs), mcts_bindings.cpp:52 / BatchedMCTS.h:52-58.  device < 0 uses
+ * the current HIP device. */
+int  az_mcts_create(int game, int n_envs, int device, az_mcts **out);
+void az_mcts_destroy(az_mcts *m);
+/* `.config` property, mcts_bindings.cpp:55-58 */
+az_search_config *az_mcts_config(az_mcts *m);
+/* get_num_envs, mcts_bindings.cpp:68 */
+int  az_mcts_num_envs(const az_mcts *m);
+/* set_seed, mcts_bindings.cpp:61 / BatchedMCTS.h:68-84.  Seeds the host mt19937 that feeds
+ * symmetry ids and Dirichlet noise in "reference RNG" mode (== the reference run with
+ * OMP_NUM_THREADS=1) and the counter-based device generator used by the dev entry points. */
+int  az_mcts_set_seed(az_mcts *m, int seed);
+/* reset_env, mcts_bindings.cpp:65 / BatchedMCTS.h:93-99 (out-of-range index is ignored) */
+int  az_mcts_reset_env(az_mcts *m, int env);
+/* prune_roots, mcts_bindings.cpp:72-81 / MCTS.h:90-132; n must equal n_envs */
+int  az_mcts_prune_roots(az_mcts *m, const int32_t *actions, int64_t n);
+
+/* ---- host entry points (reference signatures) ----------------------------------------- */
+
+/* search_batch, mcts_bindings.cpp:89-134 / BatchedMCTS.h:119-171 */
+int az_mcts_search_batch(az_mcts *m, const int8_t *boards, const int32_t *turns, int64_t n,
+                         int8_t *out_boards, float *out_term_d, float *out_term_p1w,
+                         float *out_term_p2w, uint8_t *out_is_term, int32_t *out_turns,
+                         uint8_t *out_valid_mask);
+/* backprop_batch, mcts_bindings.cpp:139-179 / BatchedMCTS.h:176-199 */
+int az_mcts_backprop_batch(az_mcts *m, const float *policy, const float *d, const float *p1w,
+                           const float *p2w, const float *moves_left, const uint8_t *is_term,
+                           int64_t n);
+/* remove_all_vl, mcts_bindings.cpp:184-191 / BatchedMCTS.h:209-216 */
+int az_mcts_remove_all_vl(az_mcts *m, int K);
+/* search_batch_vl, mcts_bindings.cpp:197-252 / BatchedMCTS.h:227-286 */
+int az_mcts_search_batch_vl(az_mcts *m, int K, const int8_t *boards, const int32_t *turns,
+                            int64_t n, int8_t *out_boards, float *out_term_d,
+                            float *out_term_p1w, float *out_term_p2w, uint8_t *out_is_term,
+                            int32_t *out_turns, int32_t *out_sym_ids, uint8_t *out_valid_mask);
+/* backprop_batch_vl, mcts_bindings.cpp:257-306 / BatchedMCTS.h:296-332; total must be n_envs*K */
+int az_mcts_backprop_batch_vl(az_mcts *m, int K, const float *policy, const float *d,
+                              const float *p1w, const float *p2w, const float *moves_left,
+                              const uint8_t *is_term, const int32_t *sym_ids, int64_t total);
+/* search(RolloutEvaluator, ...), mcts_bindings.cpp:313-337 / BatchedMCTS.h:339-407 with
+ * RolloutEvaluator.h:23-48: whole playout loop on the device, random playouts as evaluator */
+int az_mcts_search_rollout(az_mcts *m, const int8_t *boards, const int32_t *turns, int64_t n,
+                           int n_playout);
+/* get_all_counts, mcts_bindings.cpp:342 / BatchedMCTS.h:413-427: out[n_envs*A] */
+int az_mcts_get_all_counts(az_mcts *m, int32_t *out);
+/* get_all_root_stats, mcts_bindings.cpp:348-356 / MCTS.h:637-673: out[n_envs*(6+8A)] */
+int az_mcts_get_all_root_stats(az_mcts *m, float *out);
+
+/* ---- device entry points (fused loop; no reference equivalent - they are what removes the
+ *      four host crossings per iteration of MCTS_cpp.py:250-357) --------------------------- */
+
+/* Must be called OUTSIDE any stream capture before the other dev_* calls and again whenever
+ * the live config changed: sizes the leaf buffers for K descents per tree, refreshes the
+ * c_puct table, and guarantees arena room for `sims_per_tree` more simulations per tree
+ * (grows the arenas if needed; synchronises). */
+int az_mcts_dev_prepare(az_mcts *m, int K, int64_t sims_per_tree);
+/* Root positions as bitboards already in HBM: bb_p1/bb_p2 uint64[n_envs], turn int32[n_envs]
+ * (the reference passes int8 grids on every call, BatchedMCTS.h:136-137,244-245). */
+int az_mcts_dev_set_roots(az_mcts *m, const uint64_t *bb_p1, const uint64_t *bb_p2,
+                          const int32_t *turns, void *stream);
+/* Same from int8 grids in HBM (device pointer), boards[n_envs*board_size]. */
+int az_mcts_dev_import_roots(az_mcts *m, const int8_t *boards, const int32_t *turns, void *stream);
+/* K descents per tree (K=1, vl=0: simulate; vl=1: simulate_vl), then gather of the leaves into
+ * the evaluator's input: features float32[n_envs*K,3,rows,cols] in the reference's relative
+ * planes (MCTS_cpp.py:15-20), action mask uint8[n_envs*K,A] (0 for terminal leaves).
+ * Symmetry ids come from the device generator. */
+int az_mcts_dev_select(az_mcts *m, int K, int vl, float *features, uint8_t *valid_mask,
+                       void *stream);
+/* Expansion + backup straight from the evaluator's outputs: probs float32[n*K,A] (leaf frame,
+ * possibly mirrored), wdl_rel float32[n*K,3] = [draw, win, loss] for the side to move
+ * (converted as MCTS_cpp.py:23-30), moves_left float32[n*K].  Terminal leaves ignore the
+ * evaluator and use their cached result (MCTS_cpp.py:275-282). */
+int az_mcts_dev_backprop(az_mcts *m, int K, int vl, const float *probs, const float *wdl_rel,
+                         const float *moves_left, void *stream);
+/* Leaf positions of the last dev_select (unsymmetrised): bb_p1/bb_p2 uint64[n*K],
+ * turn int32[n*K], flags uint8[n*K] (bit 0 = terminal, bits 1-2 = result 0 draw / 1 P1 /
+ * 2 P2).  Any pointer may be NULL. */
+int az_mcts_dev_leaves(az_mcts *m, int K, uint64_t *bb_p1, uint64_t *bb_p2, int32_t *turns,
+                       uint8_t *flags, void *stream);
+/* Root visit counts int32[n_envs*A] / root stats float32[n_envs*(6+8A)] into HBM. */
+int az_mcts_dev_counts(az_mcts *m, int32_t *counts, void *stream);
+int az_mcts_dev_root_stats(az_mcts *m, float *stats, void *stream);
+/* prune_roots with actions in HBM and Dirichlet noise from the device generator. */
+int az_mcts_dev_prune_roots(az_mcts *m, const int32_t *actions, void *stream);
+/* Reset the trees whose mask byte is non-zero (mask uint8[n_envs] in HBM). */
+int az_mcts_dev_reset_masked(az_mcts *m, const uint8_t *mask, void *stream);
+
+/* ---- capacity / instrumentation ------------------------------------------------------- */
+
+/* Make every tree arena hold at least `slots` node records (grows, never shrinks). */
+int az_mcts_reserve(az_mcts *m, int64_t slots_per_tree);
+int64_t az_mcts_capacity(const az_mcts *m);
+/* Largest number of node records any tree uses right now (synchronises). */
+int az_mcts_max_used(az_mcts *m, int64_t *out);
+
+/* Workload counters since creation / last reset (synchronises):
+ * [0] simulations [1] select levels [2] expansions [3] terminal leaves [4] duplicate VL
+ * leaves [5] nodes updated by backup [6] select launches [7] backprop launches */
+#define AZ_NUM_COUNTERS 8
+int az_mcts_counters(az_mcts *m, int64_t out[AZ_NUM_COUNTERS]);
+int az_mcts_counters_reset(az_mcts *m);
+
+/* Test hook for the host generator: `count` Dirichlet-gamma draws from one fresh
+ * gamma(alpha,1) object on an mt19937 seeded with `seed` (checked against libstdc++). */
+int az_rng_gamma_selftest(uint32_t seed, float alpha, int count, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
