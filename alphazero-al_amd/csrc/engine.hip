@@ -78,6 +78,43 @@ struct LeafStore {
     }
 };
 
+// event pairs around one kind of kernel
+struct EventRing {
+    std::vector<hipEvent_t> start, stop;
+    size_t used = 0;
+    ~EventRing()
+    {
+        for (auto e : start) (void)hipEventDestroy(e);
+        for (auto e : stop) (void)hipEventDestroy(e);
+    }
+    void allocate(size_t n)
+    {
+        while (start.size() < n) {
+            hipEvent_t a, b;
+            HIP_OK(hipEventCreate(&a));
+            HIP_OK(hipEventCreate(&b));
+            start.push_back(a); stop.push_back(b);
+        }
+    }
+    bool begin(hipStream_t s)
+    {
+        if (used >= start.size()) return false;
+        HIP_OK(hipEventRecord(start[used], s));
+        return true;
+    }
+    void end(hipStream_t s) { HIP_OK(hipEventRecord(stop[used], s)); ++used; }
+    void read(double &ms, int64_t &n)
+    {
+        ms = 0.0; n = 0;
+        for (size_t i = 0; i < used; ++i) {
+            float t = 0.f;
+            HIP_OK(hipEventElapsedTime(&t, start[i], stop[i]));
+            ms += t; ++n;
+        }
+        used = 0;
+    }
+};
+
 constexpr int A = az::C4_ACTIONS;
 constexpr int CELLS = az::C4_CELLS;
 constexpr int STATS = az::C4_STATS;
@@ -98,6 +135,7 @@ struct az_mcts {
     DevBuf<int32_t> root, used;
     int64_t S = 0;
     int64_t used_bound = 1;   // host-side upper bound of max(used[])
+    int64_t epoch = 0;        // bumped whenever a buffer the dev_* kernels address moves
 
     // roots of the current call
     DevBuf<uint64_t> r_bb0, r_bb1;
@@ -115,6 +153,8 @@ struct az_mcts {
     DevBuf<int> err;
     DevBuf<uint64_t> call_ctr;
     int64_t select_launches = 0, backprop_launches = 0;
+    bool profiling = false;
+    EventRing ev_select, ev_backprop;
 
     // IO buffers of the host entry points
     DevBuf<int8_t> io_boards_in, io_boards_out;
@@ -153,6 +193,7 @@ struct az_mcts {
             const float parent_n = static_cast<float>(n);
             h[n] = c_init + std::log((parent_n + c_base + 1.0f) / c_base);
         }
+        if (!tab.p) ++epoch;
         tab.ensure(kCpuctTab);
         HIP_OK(hipMemcpy(tab.p, h.data(), sizeof(float) * kCpuctTab, hipMemcpyHostToDevice));
         tab_c_init = c_init; tab_c_base = c_base;
@@ -203,6 +244,7 @@ struct az_mcts {
         std::swap(hot.p, nh.p); std::swap(hot.n, nh.n);
         std::swap(cold.p, nc.p); std::swap(cold.n, nc.n);
         S = new_S;
+        ++epoch;
     }
 
     // room for `extra` more records in every tree (an expansion appends at most A records)
@@ -591,11 +633,11 @@ int az_mcts_dev_prepare(az_mcts *m, int K, int64_t sims_per_tree)
         require(K >= 1, "dev_prepare: K must be >= 1");
         HIP_OK(hipSetDevice(m->device));
         m->flush_resets(nullptr);
+        if (static_cast<size_t>(m->B) * K > m->vl_leaf.slot.n) ++m->epoch;
         m->vl_leaf.ensure(static_cast<size_t>(m->B) * K);
         m->plain_leaf.ensure(m->B);
         m->ensure_table();
         m->ensure_room(sims_per_tree * A);
-        HIP_OK(hipDeviceSynchronize());
     });
 }
 
@@ -625,7 +667,9 @@ int az_mcts_dev_select(az_mcts *m, int K, int vl, float *features, uint8_t *vali
         if (vl) m->vl_stride = K;
         m->last_select_vl = vl != 0;
         const az::SearchParams p = m->params();
+        const bool timed = m->profiling && m->ev_select.begin(s);
         az::launch_select(m->arena(), m->roots(), ls.view(), p, K, vl != 0, m->counters.p, s);
+        if (timed) m->ev_select.end(s);
         az::launch_export(ls.view(), p, static_cast<int>(total), true, nullptr, valid_mask, features, s);
         az::launch_bump_call(m->call_ctr.p, s);
         ++m->select_launches;
@@ -643,8 +687,10 @@ int az_mcts_dev_backprop(az_mcts *m, int K, int vl, const float *probs, const fl
         in.policy = probs; in.wdl_rel = wdl_rel; in.moves_left = moves_left;
         in.root_noise = nullptr; in.sym = nullptr;
         hipStream_t s = static_cast<hipStream_t>(stream);
+        const bool timed = m->profiling && m->ev_backprop.begin(s);
         az::launch_backprop(m->arena(), ls.view(), m->params(), K, vl != 0, true, in, m->counters.p,
                             m->err.p, s);
+        if (timed) m->ev_backprop.end(s);
         az::launch_bump_call(m->call_ctr.p, s);
         ++m->backprop_launches;
     });
@@ -700,6 +746,18 @@ int az_mcts_reserve(az_mcts *m, int64_t slots_per_tree)
 }
 
 int64_t az_mcts_capacity(const az_mcts *m) { return m->S; }
+int64_t az_mcts_epoch(const az_mcts *m) { return m->epoch; }
+
+int az_c4_dev_step(uint64_t *bb_p1, uint64_t *bb_p2, int32_t *turns, const int32_t *actions,
+                   uint8_t *done, int32_t *winner, int64_t n, int reset_finished, void *stream)
+{
+    return guarded([&] {
+        require(n >= 0, "az_c4_dev_step: negative size");
+        if (n == 0) return;
+        az::launch_c4_step(bb_p1, bb_p2, turns, actions, done, winner, n, reset_finished != 0,
+                           static_cast<hipStream_t>(stream));
+    });
+}
 
 int az_mcts_max_used(az_mcts *m, int64_t *out)
 {
@@ -733,6 +791,28 @@ int az_mcts_counters_reset(az_mcts *m)
         HIP_OK(hipDeviceSynchronize());
         HIP_OK(hipMemset(m->counters.p, 0, sizeof(unsigned long long) * az::CNT_N));
         m->select_launches = m->backprop_launches = 0;
+    });
+}
+
+int az_mcts_profile(az_mcts *m, int enable)
+{
+    return guarded([&] {
+        HIP_OK(hipSetDevice(m->device));
+        if (enable) {
+            m->ev_select.allocate(AZ_PROFILE_MAX);
+            m->ev_backprop.allocate(AZ_PROFILE_MAX);
+        }
+        m->profiling = enable != 0;
+    });
+}
+
+int az_mcts_profile_read(az_mcts *m, double out_ms[2], int64_t out_launches[2])
+{
+    return guarded([&] {
+        HIP_OK(hipSetDevice(m->device));
+        HIP_OK(hipDeviceSynchronize());
+        m->ev_select.read(out_ms[0], out_launches[0]);
+        m->ev_backprop.read(out_ms[1], out_launches[1]);
     });
 }
 

@@ -768,6 +768,32 @@ __global__ void __launch_bounds__(WAVE) k_root_query(TreeArena ar, int32_t *coun
     }
 }
 
+// ------------------------------------------------------------------ batched game step
+
+// Connect4.h:159-172 (step) + 182-203 / 221-224 (result) on HBM-resident positions
+__global__ void __launch_bounds__(256) k_c4_step(uint64_t *bb0, uint64_t *bb1, int32_t *turns,
+                                                 const int32_t *actions, uint8_t *done,
+                                                 int32_t *winner, int64_t n, int reset_finished)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int a = actions[i];
+    if (a < 0 || a >= C4_COLS) { done[i] = 0; winner[i] = 0; return; }
+    uint64_t b0 = bb0[i], b1 = bb1[i];
+    int turn = turns[i];
+    const uint64_t colmask = 0x7Full << (C4_BITS_PER_COL * a);
+    const uint64_t mv = (((b0 | b1) & colmask) + (1ull << (C4_BITS_PER_COL * a))) & colmask;
+    const int mover = (turn == 1) ? 0 : 1;
+    if (mover == 0) b0 |= mv; else b1 |= mv;
+    turn = -turn;
+    const int res = c4_result(b0, b1, mover);
+    const bool fin = res >= 0;
+    done[i] = fin ? 1 : 0;
+    winner[i] = res == 1 ? 1 : (res == 2 ? -1 : 0);
+    if (fin && reset_finished) { b0 = 0; b1 = 0; turn = 1; }
+    bb0[i] = b0; bb1[i] = b1; turns[i] = turn;
+}
+
 inline int groups_grid(int B) { return (B + TREES_PER_WAVE - 1) / TREES_PER_WAVE; }
 
 }  // namespace
@@ -850,6 +876,13 @@ void launch_root_stats(TreeArena ar, float *stats, hipStream_t s)
 {
     hipLaunchKernelGGL(k_root_query<true>, dim3(groups_grid(ar.B)), dim3(WAVE), 0, s, ar,
                        static_cast<int32_t *>(nullptr), stats);
+}
+
+void launch_c4_step(uint64_t *bb0, uint64_t *bb1, int32_t *turns, const int32_t *actions,
+                    uint8_t *done, int32_t *winner, int64_t n, bool reset_finished, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_c4_step, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, bb0, bb1,
+                       turns, actions, done, winner, n, reset_finished ? 1 : 0);
 }
 
 void launch_init_trees(TreeArena ar, hipStream_t s)

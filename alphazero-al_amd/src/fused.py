@@ -1,0 +1,198 @@
+"""Device-resident search loop: select -> leaf gather -> network -> expand/backup with no host
+round trip.
+
+The reference crosses Python<->C++ twice and host<->device twice per MCTS iteration
+(src/MCTS_cpp.py:250-357, Connect4/Network.py:267-288).  Here one iteration is
+    az_mcts_dev_select     HIP: K descents per tree + gather of the leaves into the
+                           evaluator's (n,3,6,7) input and (n,7) action mask, all in HBM
+    net(...)               PyTorch-ROCm on the same stream (bf16 autocast as the reference)
+    az_mcts_dev_backprop   HIP: relative->absolute WDL, expansion, backup
+enqueued back to back on the current stream, and - once shapes are warm - replayed from a
+hipGraph (torch.cuda.CUDAGraph), so the host issues one graph launch per iteration.
+
+Randomness (symmetry ids, Dirichlet noise) comes from the engine's counter-based device
+generator on this path; the bit-exact reference stream (host mt19937) needs the host path.
+With use_symmetry=False and dirichlet_alpha<=0 nothing random is consumed and this path is
+bit-identical to the host path (tests/test_fused_gpu.py).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(os.path.join(os.path.dirname(_HERE), "lib", "libaz_mcts.so"))
+        vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
+        L.az_last_error.restype = C.c_char_p
+        L.az_mcts_dev_prepare.argtypes = [vp, i32, i64]
+        L.az_mcts_dev_set_roots.argtypes = [vp, vp, vp, vp, vp]
+        L.az_mcts_dev_import_roots.argtypes = [vp, vp, vp, vp]
+        L.az_mcts_dev_select.argtypes = [vp, i32, i32, vp, vp, vp]
+        L.az_mcts_dev_backprop.argtypes = [vp, i32, i32, vp, vp, vp, vp]
+        L.az_mcts_dev_leaves.argtypes = [vp, i32, vp, vp, vp, vp, vp]
+        L.az_mcts_dev_counts.argtypes = [vp, vp, vp]
+        L.az_mcts_dev_root_stats.argtypes = [vp, vp, vp]
+        L.az_mcts_dev_prune_roots.argtypes = [vp, vp, vp]
+        L.az_mcts_dev_reset_masked.argtypes = [vp, vp, vp]
+        L.az_mcts_reserve.argtypes = [vp, i64]
+        L.az_mcts_capacity.argtypes = [vp]; L.az_mcts_capacity.restype = i64
+        L.az_mcts_epoch.argtypes = [vp]; L.az_mcts_epoch.restype = i64
+        L.az_mcts_max_used.argtypes = [vp, C.POINTER(i64)]
+        L.az_mcts_counters.argtypes = [vp, C.POINTER(i64 * 8)]
+        L.az_mcts_counters_reset.argtypes = [vp]
+        L.az_mcts_profile.argtypes = [vp, i32]
+        L.az_mcts_profile_read.argtypes = [vp, C.POINTER(C.c_double * 2), C.POINTER(i64 * 2)]
+        L.az_c4_dev_step.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, vp]
+        _LIB = L
+    return _LIB
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError(lib().az_last_error().decode())
+
+
+def is_device_module(pv):
+    if not isinstance(pv, torch.nn.Module):
+        return False
+    p = next(pv.parameters(), None)
+    if p is None:
+        p = next(pv.buffers(), None)
+    if p is None:
+        return bool(getattr(pv, "is_device_evaluator", False))
+    return p.is_cuda
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def counters(handle):
+    arr = (C.c_int64 * 8)()
+    check(lib().az_mcts_counters(handle, C.byref(arr)))
+    names = ("sims", "levels", "expansions", "terminal", "dup_leaves", "backup_nodes",
+             "select_launches", "backprop_launches")
+    return dict(zip(names, list(arr)))
+
+
+class FusedSearch:
+    """One instance per (BatchedMCTS wrapper, network) pair."""
+
+    def __init__(self, wrapper, net):
+        self.w = wrapper
+        self.net = net
+        self.h = C.c_void_p(wrapper.mcts.handle)
+        self.B = wrapper.batch_size
+        self.A = wrapper.action_size
+        p = next(net.parameters(), None)
+        self.device = p.device if p is not None else torch.device("cuda", torch.cuda.current_device())
+        # hipGraph replay pays when launches, not kernels, bound an iteration: small leaf batches
+        g = os.environ.get("AZ_FUSED_GRAPH", "auto")
+        self.use_graph = (self.B <= 512) if g == "auto" else g != "0"
+        self.autocast = os.environ.get("AZ_FUSED_AUTOCAST", "1") != "0"
+        self._bufs = {}      # K -> (features, mask)
+        self._graphs = {}    # (K, vl, cfg key, epoch) -> CUDAGraph
+        self._eager_runs = {}
+        self.aux_scale = float(getattr(net, "aux_target_offset", 1.0))
+
+    # ------------------------------------------------------------------ pieces
+    def _buffers(self, K):
+        if K not in self._bufs:
+            n = self.B * K
+            self._bufs[K] = (torch.empty((n, 3) + tuple(self.w.board_shape), dtype=torch.float32, device=self.device),
+                             torch.empty((n, self.A), dtype=torch.uint8, device=self.device))
+        return self._bufs[K]
+
+    def evaluate(self, features, mask_u8):
+        """What `predict` computes (Connect4/Network.py:267-288), kept on the device."""
+        mask = mask_u8.view(torch.bool) if mask_u8.dtype == torch.uint8 else mask_u8
+        if hasattr(self.net, "predict_device"):
+            probs, wdl, ml = self.net.predict_device(features, mask)
+        else:
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.autocast):
+                log_prob, value_lp, steps = self.net(features, action_mask=mask)
+            probs = log_prob.float().exp()
+            wdl = value_lp.exp().float()
+            ml = (steps * self.aux_scale).float()
+        return probs.contiguous(), wdl.contiguous(), ml.reshape(-1).contiguous()
+
+    def _iteration(self, K, vl):
+        L = lib()
+        feats, mask = self._buffers(K)
+        s = _stream()
+        check(L.az_mcts_dev_select(self.h, K, vl, feats.data_ptr(), mask.data_ptr(), s))
+        probs, wdl, ml = self.evaluate(feats, mask)
+        check(L.az_mcts_dev_backprop(self.h, K, vl, probs.data_ptr(), wdl.data_ptr(), ml.data_ptr(), s))
+        return probs, wdl, ml      # keep alive until enqueued work is ordered behind them
+
+    def _cfg_key(self):
+        c = self.w.mcts.config
+        return (c.c_init, c.c_base, c.dirichlet_alpha, c.noise_epsilon, c.fpu_reduction, c.mlh_slope,
+                c.mlh_cap, c.value_decay, bool(c.use_symmetry), c.vl_count)
+
+    def _run(self, K, vl):
+        """One iteration: eager for the first two runs of a shape (lets MIOpen / hipBLASLt pick
+        kernels and allocate workspaces), then captured once and replayed."""
+        if not self.use_graph:
+            self._keep = self._iteration(K, vl)
+            return
+        key = (K, vl, self._cfg_key(), lib().az_mcts_epoch(self.h))
+        g = self._graphs.get(key)
+        if g is not None:
+            g.replay()
+            return
+        runs = self._eager_runs.get(key, 0)
+        if runs < 2:
+            self._eager_runs[key] = runs + 1
+            self._keep = self._iteration(K, vl)
+            return
+        # drop graphs of stale epochs / configs for this shape
+        for k in [k for k in self._graphs if k[0] == K and k[1] == vl]:
+            del self._graphs[k]
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            outs = self._iteration(K, vl)
+        self._graphs[key] = g
+        self._graph_outs = getattr(self, "_graph_outs", {})
+        self._graph_outs[key] = outs
+        g.replay()           # capture does not execute: this is the real iteration
+
+    # ------------------------------------------------------------------ public
+    def upload_roots(self, boards, turns):
+        b = torch.from_numpy(np.ascontiguousarray(boards, dtype=np.int8)).to(self.device, non_blocking=False)
+        t = torch.from_numpy(np.ascontiguousarray(turns, dtype=np.int32)).to(self.device, non_blocking=False)
+        check(lib().az_mcts_dev_import_roots(self.h, b.data_ptr(), t.data_ptr(), _stream()))
+        self._roots_keep = (b, t)
+
+    def search(self, n_playout, vl_batch):
+        """The reference's iteration schedule (MCTS_cpp.py:110-113, 217-264) on roots that are
+        already in HBM."""
+        K = max(1, int(vl_batch))
+        check(lib().az_mcts_dev_prepare(self.h, K, int(n_playout)))
+        if K <= 1:
+            for _ in range(n_playout):
+                self._run(1, 0)
+            return
+        remaining = n_playout
+        if remaining > 0:
+            self._run(1, 0)          # warm-up simulation expands every root
+            remaining -= 1
+        while remaining > 0:
+            k = min(K, remaining)
+            remaining -= k
+            self._run(k, 1)
+
+    def playout(self, boards, turns, n_playout, vl_batch):
+        with torch.cuda.device(self.device):
+            self.upload_roots(boards, turns)
+            self.search(n_playout, vl_batch)
+            if torch.cuda.current_stream().cuda_stream != 0:
+                torch.cuda.current_stream().synchronize()   # host entry points use the NULL stream

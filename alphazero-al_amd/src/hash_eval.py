@@ -1,0 +1,64 @@
+"""Deterministic integer-hash evaluator that lives on the GPU.
+
+Not a model: a pure function of (bitboards, side to move) built from 64-bit integer mixing,
+small integers and one correctly rounded fp32 division, so that numpy on the host, torch on
+the device and a HIP kernel all produce bit-identical policy / WDL / moves-left values
+(tests/scenarios.py holds the numpy twin).  Used to check the fused search path bit-for-bit
+against the CPU oracle and to benchmark the tree kernels without a network.
+"""
+import torch
+
+
+def _c(v):
+    """uint64 constant as the int64 bit pattern torch computes with."""
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def _xorshift(x, s):
+    return x ^ ((x >> s) & ((1 << (64 - s)) - 1))      # logical shift on int64
+
+
+class HashEvaluator(torch.nn.Module):
+    """Follows the device-evaluator protocol of fused.FusedSearch: `predict_device(features,
+    mask) -> (probs[n,7], wdl_rel[n,3], moves_left[n])`, all float32 tensors on the device."""
+    is_device_evaluator = True
+    n_actions = 7
+
+    def __init__(self, device="cuda"):
+        super().__init__()
+        self.register_buffer("anchor", torch.zeros(1, device=device))
+
+    @torch.no_grad()
+    def predict_device(self, feats, mask):
+        dev = feats.device
+        turn = feats[:, 2, 0, 0].to(torch.int64)
+        grid = ((feats[:, 0] - feats[:, 1]) * feats[:, 2]).to(torch.int64)         # +1 / -1 / 0
+        rows = torch.arange(6, device=dev).view(1, 6, 1)
+        cols = torch.arange(7, device=dev).view(1, 1, 7)
+        bit = torch.ones((), dtype=torch.int64, device=dev) << (cols * 7 + (5 - rows))
+        bb0 = (bit * (grid == 1)).sum((1, 2))
+        bb1 = (bit * (grid == -1)).sum((1, 2))
+        x = bb0 * _c(0x9E3779B97F4A7C15)
+        x = x ^ ((bb1 + _c(0x7F4A7C159E3779B9)) * _c(0xBF58476D1CE4E5B9))
+        x = x + torch.where(turn == 1, torch.full_like(x, _c(0x94D049BB133111EB)),
+                            torch.full_like(x, _c(0x2545F4914F6CDD1D)))
+        x = _xorshift(x, 30) * _c(0xBF58476D1CE4E5B9)
+        x = _xorshift(x, 27) * _c(0x94D049BB133111EB)
+        x = _xorshift(x, 31)
+        sh = torch.arange(7, device=dev) * 4
+        probs = (1 + ((x.unsqueeze(1) >> sh) & 15)).to(torch.float32) / 16.0
+        probs = probs * mask.to(torch.float32)
+        w = torch.stack([1 + ((x >> s) & 31) for s in (28, 33, 38)], 1)
+        wdl = w.to(torch.float32) / w.sum(1, keepdim=True).to(torch.float32)
+        ml = ((x >> 43) & 63).to(torch.float32) / 2.0
+        return probs, wdl, ml
+
+    @torch.no_grad()
+    def predict(self, state, action_mask=None):
+        """numpy contract of the reference's `predict`, for the host path."""
+        import numpy as np
+        f = torch.as_tensor(np.asarray(state), dtype=torch.float32, device=self.anchor.device)
+        m = torch.ones((f.shape[0], 7), dtype=torch.bool, device=f.device) if action_mask is None \
+            else torch.as_tensor(np.asarray(action_mask), device=f.device).to(torch.bool)
+        p, w, ml = self.predict_device(f, m)
+        return p.cpu().numpy(), w.cpu().numpy(), ml.view(-1, 1).cpu().numpy()

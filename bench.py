@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Connect4 self-play, n_playout=200, 8192 games per GPU, vl_batch=4
+(BASELINE.json configs[1]) - positions/s and node-expansions/s on N GPUs of one node.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one ply played in every one of the 8192 games of a rank: 200 simulations per
+tree (1 warm-up + 50 virtual-loss iterations of 4), each iteration = HIP selection + leaf
+gather -> the reference's CNN (random init, bf16 autocast, PyTorch-ROCm) -> HIP
+expansion/backup, then action sampling, re-rooting with fresh Dirichlet noise and the game
+step, all resident in HBM (alphazero-al_amd/src/selfplay.py).  Ranks hold independent game
+shards (weak scaling); the only collective is one all-reduce of the counters at the end.
+
+Output: ONE JSON line on rank 0.  `value` = positions/s of the whole job.  `roofline` is for
+the dominant hand-written kernel (tree selection): algorithmic bytes per launch (SURVEY.md
+8(d): 28+29E per level with E=7, plus 16 B of leaf state per simulation, from the engine's
+own level/simulation counters) over the kernel's mean duration measured with HIP events on
+the launch stream during the timed region.  `cpu_baseline` times the reference's C++/OpenMP
+search (oracle/_ref, compiled from the reference's sources) with the same network on the
+host cores, on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "alphazero-al_amd")
+for p in (PKG, ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+SEL_BYTES_PER_LEVEL = 28 + 29 * 7   # parent 28 B + 7 x (edge 8 B + child 21 B)
+LEAF_STATE_BYTES = 16               # two u64 bitboards written per simulation
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--games", type=int, default=8192, help="games (trees) per GPU")
+    ap.add_argument("--n-playout", type=int, default=200)
+    ap.add_argument("--vl-batch", type=int, default=4)
+    ap.add_argument("--evaluator", choices=["cnn", "hash"], default="cnn",
+                    help="cnn: the reference's network (headline); hash: integer hash evaluator (tree kernels only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-games", type=int, default=256)
+    ap.add_argument("--cpu-plies", type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, rank):
+    """Reference C++/OpenMP search (oracle/_ref) + the same CNN on the host CPU, through the
+    reference-compatible wrapper, on a bounded sample of the same workload."""
+    import numpy as np
+    import torch
+    ref_dirs = [os.path.join(ROOT, "oracle", "_ref", v) for v in ("portable", "native")]
+    ref_dir = next((d for d in ref_dirs if os.path.isdir(os.path.join(d, "src"))), None)
+    if ref_dir is None:
+        return None
+    cores = len(os.sched_getaffinity(0))
+    code = f"""
+import sys, time, json, os
+import numpy as np, torch
+sys.path[:0] = [{ref_dir!r}, {PKG!r}]
+from src import mcts_cpp                       # the REFERENCE's compiled module (oracle/_ref)
+import importlib.util
+spec = importlib.util.spec_from_file_location('az_wrap', os.path.join({PKG!r}, 'src', 'MCTS_cpp.py'))
+W = importlib.util.module_from_spec(spec); spec.loader.exec_module(W)
+spec = importlib.util.spec_from_file_location('az_net', os.path.join({PKG!r}, 'src', 'az_net.py'))
+N = importlib.util.module_from_spec(spec); spec.loader.exec_module(N)
+torch.manual_seed(0); torch.set_num_threads({cores})
+net = N.Connect4Net(device='cpu').eval()
+B, n, K, plies = {args.cpu_games}, {args.n_playout}, {args.vl_batch}, {args.cpu_plies}
+w = W.BatchedMCTS(B, c_init=1.4, c_base=5*n, alpha=0.3, n_playout=n, noise_epsilon=0.25,
+                  fpu_reduction=0.2, use_symmetry=True, mlh_slope=0.1, mlh_cap=0.2)
+w.seed(0)
+boards = np.zeros((B, 6, 7), np.int8); turns = np.ones(B, np.int32)
+t0 = time.perf_counter()
+for ply in range(plies):
+    w.batch_playout(net, boards, turns, vl_batch=K, fused=False)
+    c = w.get_visits_count(); a = c.argmax(1).astype(np.int32)
+    w.prune_roots(a)
+    for i in range(B):
+        col = boards[i][:, a[i]]; r = np.where(col == 0)[0].max(); boards[i][r, a[i]] = turns[i]
+    turns = -turns
+dt = time.perf_counter() - t0
+print(json.dumps(dict(value=B*plies/dt, seconds=dt, positions=B*plies)))
+"""
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS=str(cores), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    try:
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+        r = json.loads(line)
+    except Exception as e:                      # the baseline is a reported extra, never fatal
+        sys.stderr.write(f"cpu_baseline failed: {e}\n")
+        return None
+    return {"value": round(r["value"], 2), "unit": "positions/s", "cores": cores, "kind": "reference",
+            "sample": f"{args.cpu_games} games x {args.cpu_plies} plies, n_playout={args.n_playout}, "
+                      f"vl_batch={args.vl_batch}, reference C++/OpenMP search (oracle/_ref/{os.path.basename(ref_dir)}) "
+                      f"+ same CNN fp32 on CPU, {r['seconds']:.1f} s"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the search engine has no CPU path)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))   # RCCL
+
+    import __graft_entry__ as ge
+    if rank == 0 and not os.path.exists(os.path.join(PKG, "lib", "libaz_mcts.so")):
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    from src import fused as F
+    from src.az_net import Connect4Net
+    from src.selfplay import DeviceSelfPlay
+
+    dev = torch.device("cuda", local)
+    torch.manual_seed(1234)                     # same random-init weights on every rank
+    if args.evaluator == "hash":
+        from src.hash_eval import HashEvaluator
+        net = HashEvaluator(dev)
+    else:
+        net = Connect4Net(device=dev).eval()
+    sp = DeviceSelfPlay(net, args.games, n_playout=args.n_playout, vl_batch=args.vl_batch, seed=rank,
+                        reserve_slots=int(os.environ.get("AZ_RESERVE_SLOTS", "49152")))
+    L = F.lib()
+
+    for _ in range(args.warmup):
+        sp.step()
+    torch.cuda.synchronize()
+    F.check(L.az_mcts_counters_reset(sp.h))
+    F.check(L.az_mcts_profile(sp.h, 1))
+    t_before = sp.read_totals()
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sp.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    import ctypes as C
+    ms = (C.c_double * 2)(); nl = (C.c_int64 * 2)()
+    F.check(L.az_mcts_profile_read(sp.h, C.byref(ms), C.byref(nl)))
+    F.check(L.az_mcts_profile(sp.h, 0))
+    cnt = sp.engine_counters()
+    tot = sp.read_totals()
+    positions = tot["positions"] - t_before["positions"]
+    games = tot["games"] - t_before["games"]
+
+    # one collective: sum the counters, max the time (xGMI, a few dozen bytes)
+    vec = torch.tensor([positions, cnt["sims"], cnt["expansions"], games, cnt["levels"], cnt["backup_nodes"]],
+                       dtype=torch.int64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    g_pos, g_sims, g_exp, g_games, g_levels, g_backup = [int(v) for v in vec.tolist()]
+    t = float(tmax.item())
+
+    if rank == 0:
+        sims_rank = max(cnt["sims"], 1)
+        depth = cnt["levels"] / sims_rank
+        xps = cnt["expansions"] / sims_rank
+        sel_ms, sel_n = float(ms[0]), int(nl[0])
+        bp_ms, bp_n = float(ms[1]), int(nl[1])
+        sel_bytes = cnt["levels"] * SEL_BYTES_PER_LEVEL + cnt["sims"] * LEAF_STATE_BYTES
+        roofline = None
+        if sel_n > 0 and sel_ms > 0:
+            # counters cover every launch of the timed region; events cover the same launches
+            launches = max(cnt["select_launches"], 1)
+            per_launch_bytes = sel_bytes / launches
+            avg_ms = sel_ms / sel_n
+            achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "traffic_select.json")
+            if os.path.exists(tf):
+                try:
+                    traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                        "kernel": "k_select<VL>", "avg_launch_us": round(avg_ms * 1e3, 2),
+                        "launches_timed": sel_n, "algorithmic_bytes_per_launch": int(per_launch_bytes)}
+        out = {
+            "metric": "self-play positions/sec (Connect4 n_playout=200, batch=8192 games/GPU, vl_batch=4)",
+            "value": round(g_pos / t, 2), "unit": "positions/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(t / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 tree statistics (u64 bitboards); bf16 autocast network",
+            "data": "synthetic: self-play from empty boards, random-init network" if args.evaluator == "cnn"
+                    else "synthetic: self-play from empty boards, integer-hash evaluator",
+            "config": {"workload": "Connect4 self-play, n_playout=%d, %d games/GPU, vl_batch=%d, evaluator=%s"
+                                   % (args.n_playout, args.games, args.vl_batch, args.evaluator),
+                       "c_init": 1.4, "c_base": 5 * args.n_playout, "fpu_reduction": 0.2, "dirichlet_alpha": 0.3,
+                       "noise_epsilon": 0.25, "mlh_slope": 0.1, "use_symmetry": True,
+                       "parallelism": "independent game shards x%d" % world},
+            "sims_per_s": round(g_sims / t, 1), "node_expansions_per_s": round(g_exp / t, 1),
+            "node_expansions_per_s_per_gpu": round(g_exp / t / world, 1),
+            "games_finished": g_games, "mean_select_depth": round(depth, 3), "expansions_per_sim": round(xps, 3),
+            "backprop_kernel_avg_us": round(bp_ms / bp_n * 1e3, 2) if bp_n else None,
+            "tree_kernels_share_of_step": round((sel_ms + bp_ms) / (elapsed * 1e3), 4),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, rank)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

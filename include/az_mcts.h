@@ -153,11 +153,23 @@ int az_mcts_dev_prune_roots(az_mcts *m, const int32_t *actions, void *stream);
 /* Reset the trees whose mask byte is non-zero (mask uint8[n_envs] in HBM). */
 int az_mcts_dev_reset_masked(az_mcts *m, const uint8_t *mask, void *stream);
 
+/* Batched Connect4 positions in HBM - the device-side counterpart of Env.step / done /
+ * winPlayer (env_common.h:141-147, env_connect4.h:38-40, Connect4.h:159-203) for a self-play
+ * driver that keeps its games next to the trees: plays actions[i] in game i (bitboards and
+ * side to move updated in place), writes done[i] (1 = won or board full) and winner[i]
+ * (+1 / -1 / 0).  With reset_finished != 0 a finished game is replaced by the empty board
+ * with player +1 to move.  Games with actions[i] < 0 are left untouched (done = 0). */
+int az_c4_dev_step(uint64_t *bb_p1, uint64_t *bb_p2, int32_t *turns, const int32_t *actions,
+                   uint8_t *done, int32_t *winner, int64_t n, int reset_finished, void *stream);
+
 /* ---- capacity / instrumentation ------------------------------------------------------- */
 
 /* Make every tree arena hold at least `slots` node records (grows, never shrinks). */
 int az_mcts_reserve(az_mcts *m, int64_t slots_per_tree);
 int64_t az_mcts_capacity(const az_mcts *m);
+/* Changes whenever any device buffer the dev_* kernels address was reallocated (arena growth,
+ * wider K, new c_puct table): a captured hipGraph of dev_* calls is valid for one epoch. */
+int64_t az_mcts_epoch(const az_mcts *m);
 /* Largest number of node records any tree uses right now (synchronises). */
 int az_mcts_max_used(az_mcts *m, int64_t *out);
 
@@ -167,6 +179,15 @@ int az_mcts_max_used(az_mcts *m, int64_t *out);
 #define AZ_NUM_COUNTERS 8
 int az_mcts_counters(az_mcts *m, int64_t out[AZ_NUM_COUNTERS]);
 int az_mcts_counters_reset(az_mcts *m);
+
+/* Kernel timing with HIP events recorded on the launch stream around every selection and every
+ * expansion/backup kernel issued by the dev_* entry points (bench.py's roofline figures).
+ * enable != 0 starts recording (at most AZ_PROFILE_MAX launches per kind are kept between
+ * reads); az_mcts_profile_read synchronises and returns, for [0] selection and [1]
+ * expansion/backup, the summed kernel time in ms and the number of launches summed. */
+#define AZ_PROFILE_MAX 8192
+int az_mcts_profile(az_mcts *m, int enable);
+int az_mcts_profile_read(az_mcts *m, double out_ms[2], int64_t out_launches[2]);
 
 /* Test hook for the host generator: `count` Dirichlet-gamma draws from one fresh
  * gamma(alpha,1) object on an mt19937 seeded with `seed` (checked against libstdc++). */

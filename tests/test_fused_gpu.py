@@ -1,0 +1,205 @@
+"""GPU tests of the device-resident loop (fused.py), the network port and the self-play driver.
+
+The fused path uses the engine's device generator, so bit-exact comparisons use the
+configuration that consumes no randomness (use_symmetry=False, alpha<=0, eps=0) and the
+integer-hash evaluator; there the fused path must equal the CPU oracle bit for bit.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import scenarios as S
+from oracle import oracle as O
+from test_oracle_golden import bits, load
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "alphazero-al_amd")
+
+
+@pytest.fixture(scope="module")
+def env():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    ge.build()
+    if PKG not in sys.path:
+        sys.path.insert(0, PKG)
+    import torch
+    from src import MCTS_cpp, fused, hash_eval, az_net, selfplay
+    return dict(torch=torch, W=MCTS_cpp, F=fused, H=hash_eval, N=az_net, SP=selfplay)
+
+
+def _planes(boards, turns):
+    return np.stack([(boards == turns[:, None, None]), (boards == -turns[:, None, None]),
+                     np.ones_like(boards) * turns[:, None, None]], 1).astype(np.float32)
+
+
+def test_device_hash_evaluator_equals_numpy_twin(env):
+    rng = np.random.default_rng(0)
+    b, t = S.random_openings(rng, 500, 36)
+    mask = b[:, 0, :] == 0
+    p, w, ml = env["H"].HashEvaluator("cuda").predict(_planes(b, t), mask)
+    p2, w2, ml2 = S.hash_eval(b, t)
+    assert np.array_equal(bits(p), bits(p2 * mask)) and np.array_equal(bits(w), bits(w2))
+    assert np.array_equal(bits(ml[:, 0]), bits(ml2))
+
+
+def _oracle_plies(cfg, boards, turns, n, K, plies):
+    o = O.BatchedMCTS_Connect4(boards.shape[0])
+    S.apply_cfg(o, cfg)
+    return S.play_plies(o, boards, turns, n, K, plies)
+
+
+def _fused_plies(env, cfg, boards, turns, n, K, plies, graph):
+    os.environ["AZ_FUSED_GRAPH"] = "1" if graph else "0"
+    try:
+        B = boards.shape[0]
+        w = env["W"].BatchedMCTS(B, c_init=cfg["c_init"], c_base=cfg["c_base"], alpha=cfg["dirichlet_alpha"],
+                                 n_playout=n, noise_epsilon=cfg["noise_epsilon"], fpu_reduction=cfg["fpu_reduction"],
+                                 use_symmetry=cfg["use_symmetry"], mlh_slope=cfg["mlh_slope"], mlh_cap=cfg["mlh_cap"],
+                                 value_decay=cfg["value_decay"])
+        w.mcts.config.vl_count = cfg["vl_count"]
+        net = env["H"].HashEvaluator("cuda")
+        boards, turns = boards.copy(), turns.copy()
+        counts, stats = [], []
+        for _ in range(plies):
+            w.batch_playout(net, boards, turns, vl_batch=K)
+            assert w._fused is not None, "the device-resident path did not engage"
+            c = w.get_visits_count().astype(np.int32)
+            counts.append(c); stats.append(np.array(w.mcts.get_all_root_stats()))
+            acts = np.argmax(c, 1).astype(np.int32)
+            w.prune_roots(acts)
+            for i in range(B):
+                if not S.np_done(boards[i]) and boards[i][0, acts[i]] == 0:
+                    S.np_drop(boards[i], int(acts[i]), int(turns[i])); turns[i] = -turns[i]
+        return np.stack(counts), np.stack(stats)
+    finally:
+        os.environ.pop("AZ_FUSED_GRAPH", None)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("n,K", [(50, 4), (200, 4), (37, 1), (66, 8)])
+def test_fused_path_bit_exact_vs_oracle(env, graph, n, K):
+    rng = np.random.default_rng(n * 10 + K)
+    boards, turns = S.random_openings(rng, 96, 12)
+    cfg = dict(S.DET_CFG, c_base=5.0 * n)
+    ref = _oracle_plies(cfg, boards, turns, n, K, 4)
+    counts, stats = _fused_plies(env, cfg, boards, turns, n, K, 4, graph)
+    assert np.array_equal(counts, ref["counts"])
+    assert np.array_equal(bits(stats), bits(ref["stats"]))
+
+
+def test_fused_value_decay_and_eps_without_alpha(env):
+    rng = np.random.default_rng(77)
+    boards, turns = S.random_openings(rng, 64, 10)
+    cfg = dict(S.DET_CFG, value_decay=0.97, noise_epsilon=0.25, vl_count=2)
+    ref = _oracle_plies(cfg, boards, turns, 80, 4, 3)
+    counts, stats = _fused_plies(env, cfg, boards, turns, 80, 4, 3, False)
+    assert np.array_equal(counts, ref["counts"]) and np.array_equal(bits(stats), bits(ref["stats"]))
+
+
+def test_network_port_matches_reference_outputs_g7(env):
+    """G7: fp32 on the GPU within 1e-4 of the reference's CPU fp32 outputs; bf16 autocast
+    (what self-play uses, Network.py:275) within 2e-2.  Search parity never goes through the
+    network."""
+    torch = env["torch"]
+    g = load("g7_network"); wts = load("g7_checkpoint_weights")
+    net = env["N"].Connect4Net(device="cuda").eval()
+    planes = _planes(g["boards"], g["turns"]); masks = g["masks"].astype(bool)
+    p, w, ml = net.predict(planes, masks)            # random init, bf16 autocast
+    assert np.abs(p - g["init_probs"]).max() < 2e-2 and np.abs(w - g["init_wdl"]).max() < 2e-2
+    env["N"].load_reference_weights(net, {k: wts[k] for k in wts.files})
+    p, w, ml = net.predict(planes, masks)
+    assert np.abs(p - g["ckpt_probs"]).max() < 2e-2
+    assert np.abs(w - g["ckpt_wdl"]).max() < 2e-2
+    assert np.abs(ml - g["ckpt_ml"]).max() < 42 * 2e-2
+    with torch.no_grad():
+        lp, lv, st = net(torch.from_numpy(planes).cuda(), action_mask=torch.from_numpy(masks).cuda())
+    assert np.abs(lp.exp().cpu().numpy() - g["ckpt_probs"]).max() < 1e-4
+    assert np.abs(lv.exp().cpu().numpy() - g["ckpt_wdl"]).max() < 1e-4
+    assert np.abs(st.cpu().numpy() - g["ckpt_steps"]).max() < 1e-4
+
+
+def test_fused_with_network_statistical_agreement(env):
+    """Same network, fused path vs host path: bf16 GEMMs are batch-shape dependent, so compare
+    what must hold regardless - simulation budget, probability mass, and near-equal root Q."""
+    wts = load("g7_checkpoint_weights")
+    net = env["N"].Connect4Net(device="cuda").eval()
+    env["N"].load_reference_weights(net, {k: wts[k] for k in wts.files})
+    rng = np.random.default_rng(5)
+    boards, turns = S.random_openings(rng, 128, 8)
+    res = []
+    for fused in (True, False):
+        w = env["W"].BatchedMCTS(128, 1.4, 1000, 0.0, 200, noise_epsilon=0.0, fpu_reduction=0.2,
+                                 use_symmetry=False, mlh_slope=0.1)
+        w.batch_playout(net, boards, turns, vl_batch=4, fused=fused)
+        assert (w._fused is not None) == fused
+        res.append((w.get_visits_count(), np.array(w.mcts.get_all_root_stats())))
+    (c1, s1), (c2, s2) = res
+    assert (s1[:, 0] == 200).all() and (s2[:, 0] == 200).all()
+    assert (c1.sum(1) == 199).all() and (c2.sum(1) == 199).all()
+    assert np.abs(s1[:, 1] - s2[:, 1]).mean() < 0.05          # root Q
+    assert (np.argmax(c1, 1) == np.argmax(c2, 1)).mean() > 0.8
+
+
+def test_device_generator_noise_and_symmetry(env):
+    torch = env["torch"]
+    rng = np.random.default_rng(9)
+    boards, turns = S.random_openings(rng, 256, 6)
+    w = env["W"].BatchedMCTS(256, 1.4, 1000, 0.3, 40, noise_epsilon=0.25, fpu_reduction=0.2, use_symmetry=True)
+    w.seed(3)
+    net = env["H"].HashEvaluator("cuda")
+    w.batch_playout(net, boards, turns, vl_batch=4)
+    st = w.get_root_stats()
+    noise, prior = st["noise"], st["prior"]
+    valid = prior > 0
+    assert (noise >= 0).all() and np.allclose(noise.sum(1), 1.0, atol=1e-5)
+    assert (noise[~valid] == 0).all()
+    assert noise[valid].std() > 0.05                       # Dirichlet(0.3) is spiky, not uniform
+    # two engines with different seeds draw different noise; same seed reproduces
+    w2 = env["W"].BatchedMCTS(256, 1.4, 1000, 0.3, 40, noise_epsilon=0.25, fpu_reduction=0.2, use_symmetry=True)
+    w2.seed(3)
+    w2.batch_playout(net, boards, turns, vl_batch=4)
+    assert np.array_equal(w2.get_root_stats()["noise"], noise)
+    assert np.array_equal(w2.get_visits_count(), w.get_visits_count())
+    w3 = env["W"].BatchedMCTS(256, 1.4, 1000, 0.3, 40, noise_epsilon=0.25, fpu_reduction=0.2, use_symmetry=True)
+    w3.seed(4)
+    w3.batch_playout(net, boards, turns, vl_batch=4)
+    assert not np.array_equal(w3.get_root_stats()["noise"], noise)
+    # prune draws fresh noise for the new root
+    acts = np.argmax(w.get_visits_count(), 1).astype(np.int32)
+    F = env["F"]
+    a = torch.from_numpy(acts).cuda()
+    F.check(F.lib().az_mcts_dev_prune_roots(w._fused.h, a.data_ptr(), F._stream()))
+    torch.cuda.synchronize()
+    st2 = w.get_root_stats()
+    exp = st2["prior"].sum(1) > 0
+    assert np.allclose(st2["noise"][exp].sum(1), 1.0, atol=1e-5)
+
+
+def test_device_selfplay_driver(env):
+    torch = env["torch"]
+    net = env["H"].HashEvaluator("cuda")
+    sp = env["SP"].DeviceSelfPlay(net, 256, n_playout=40, vl_batch=4, seed=1, temp_decay_moves=6)
+    steps = 50
+    for _ in range(steps):
+        sp.step()
+    tot = sp.read_totals()
+    cnt = sp.engine_counters()
+    assert tot["positions"] == steps * 256
+    assert cnt["sims"] == steps * 256 * 40
+    assert tot["games"] > 256 and tot["games"] == tot["p1_wins"] + tot["p2_wins"] + tot["draws"]
+    # every game is a legal position: piece counts match the ply counter and the side to move
+    n0 = np.array([bin(int(v) & (2**64 - 1)).count("1") for v in sp.bb_p1.cpu().tolist()])
+    n1 = np.array([bin(int(v) & (2**64 - 1)).count("1") for v in sp.bb_p2.cpu().tolist()])
+    ply = sp.ply.cpu().numpy(); turn = sp.turn.cpu().numpy()
+    assert np.array_equal(n0 + n1, ply) and ((n0 - n1 == 0) | (n0 - n1 == 1)).all()
+    assert np.array_equal(turn, np.where(ply % 2 == 0, 1, -1))
+    assert (sp.bb_p1 & sp.bb_p2).abs().sum().item() == 0
+    # trees stay bounded by the arena and the engine reports no overflow
+    used = env["F"].C.c_int64()
+    env["F"].check(env["F"].lib().az_mcts_max_used(sp.h, env["F"].C.byref(used)))
+    assert 1 < used.value <= env["F"].lib().az_mcts_capacity(sp.h)
