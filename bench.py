@@ -37,6 +37,27 @@ SEL_BYTES_PER_LEVEL = 28 + 29 * 7   # parent 28 B + 7 x (edge 8 
 LEAF_STATE_BYTES = 16               # two u64 bitboards written per simulation
 
 
+T_START = time.perf_counter()
+
+
+def log(msg):
+    """Progress on stderr (the JSON line on stdout stays alone)."""
+    sys.stderr.write("[bench %7.1fs] %s\n" % (time.perf_counter() - T_START, msg))
+    sys.stderr.flush()
+
+
+def host_cores():
+    """CPU share of this process: affinity mask capped by the cgroup quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("AZ_CPU_CORES", "64"))))
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,7 +83,8 @@ def cpu_baseline(args, rank):
     ref_dir = next((d for d in ref_dirs if os.path.isdir(os.path.join(d, "src"))), None)
     if ref_dir is None:
         return None
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
+    log(f"cpu_baseline: reference C++/OpenMP search + CNN on {cores} host threads ...")
     code = f"""
 import sys, time, json, os
 import numpy as np, torch
@@ -94,7 +116,7 @@ print(json.dumps(dict(value=B*plies/dt, seconds=dt, positions=B*plies)))
     import subprocess
     env = dict(os.environ, OMP_NUM_THREADS=str(cores), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     try:
-        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
         r = json.loads(line)
     except Exception as e:                      # the baseline is a reported extra, never fatal
@@ -141,8 +163,12 @@ def main():
                         reserve_slots=int(os.environ.get("AZ_RESERVE_SLOTS", "49152")))
     L = F.lib()
 
-    for _ in range(args.warmup):
+    log(f"rank {rank}: engine + evaluator ready ({args.games} games, n_playout={args.n_playout}, K={args.vl_batch})")
+    for i in range(args.warmup):
+        tw = time.perf_counter()
         sp.step()
+        torch.cuda.synchronize()
+        log(f"warm-up step {i + 1}/{args.warmup}: {time.perf_counter() - tw:.2f} s")
     torch.cuda.synchronize()
     F.check(L.az_mcts_counters_reset(sp.h))
     F.check(L.az_mcts_profile(sp.h, 1))
@@ -159,6 +185,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    log(f"timed region: {args.steps} steps in {elapsed:.2f} s")
 
     import ctypes as C
     ms = (C.c_double * 2)(); nl = (C.c_int64 * 2)()
