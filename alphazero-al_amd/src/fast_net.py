@@ -1,0 +1,167 @@
+"""Inference twin of the Connect4 network, laid out for MI355X.
+
+Computes exactly what Connect4/Network.py::CNN.forward computes (same weights, same maths),
+but arranged so that a 32 768-leaf batch costs a handful of well-shaped kernels instead of
+~60 small ones:
+
+* activations stay in ONE layout - tokens (B, 42, C), which is channels-last for the 3x3
+  convolutions - so the NCHW<->NHWC transposes and the flatten/transpose before attention
+  disappear (MIOpen's NHWC bf16 implicit-GEMM kernels run on the buffers as they are);
+* weights are cast to the compute dtype once, not on every call by autocast;
+* the per-head gate projection (N=4) rides in the QKV GEMM (N=192+4), and the three N=1
+  linears (row gate, policy logit, moves-left) are dot products, not GEMMs;
+* GroupNorm(1, C) is LayerNorm over the sample's 42*C values followed by the channel affine,
+  RMSNorm uses the fused kernel (weight in the activation dtype).
+
+Statistics of the normalisations and the softmaxes accumulate in fp32 as they do under the
+reference's bf16 autocast.  `FastConnect4Net.from_module(net)` snapshots any module with the
+reference's parameter names (the reference CNN itself or az_net.Connect4Net).
+"""
+import torch
+import torch.nn.functional as F
+
+ROWS, COLS, CELLS = 6, 7, 42
+
+
+class FastConnect4Net(torch.nn.Module):
+    aux_target_offset = 42
+    n_actions = COLS
+
+    def __init__(self, state_dict, device, dtype=torch.bfloat16, heads=4):
+        super().__init__()
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.heads = heads
+        sd = {k: v.detach().to(self.device) for k, v in state_dict.items()}
+        c = lambda t: t.to(dtype).contiguous()   # noqa: E731
+        f = lambda t: t.to(torch.float32).contiguous()   # noqa: E731
+
+        self.embed_dim = sd["piece_emb.weight"].shape[1]
+        self.register_buffer("emb_own", c(sd["piece_emb.weight"][0]))
+        self.register_buffer("emb_opp", c(sd["piece_emb.weight"][1]))
+        self.register_buffer("pos", c(sd["pos_emb.weight"][sd["orbit_map"].long()]))       # (42, E)
+
+        def conv_w(w):      # OIHW -> channels_last weight
+            return c(w).contiguous(memory_format=torch.channels_last)
+        self.register_buffer("stem_w", conv_w(sd["hidden.0.weight"]))
+        self.register_buffer("stem_b", c(sd["hidden.0.bias"]))
+        self.h_dim = sd["hidden.0.weight"].shape[0]
+        self.res = []
+        i = 2
+        while f"hidden.{i}.conv.weight" in sd:
+            names = (f"res{i}_w", f"res{i}_b", f"res{i}_g", f"res{i}_beta")
+            self.register_buffer(names[0], conv_w(sd[f"hidden.{i}.conv.weight"]))
+            self.register_buffer(names[1], c(sd[f"hidden.{i}.conv.bias"]))
+            self.register_buffer(names[2], c(sd[f"hidden.{i}.norm.weight"]))
+            self.register_buffer(names[3], c(sd[f"hidden.{i}.norm.bias"]))
+            self.res.append(names)
+            i += 1
+        a = f"hidden.{i}.attn."
+        self.register_buffer("pre_w", c(sd[a + "prenorm.weight"]))
+        self.register_buffer("qkvg_w", c(torch.cat([sd[a + "qkv_proj.weight"], sd[a + "gate_proj.weight"]], 0)))
+        self.register_buffer("o_w", c(sd[a + "o_proj.weight"]))
+        self.register_buffer("qn_w", c(sd[a + "q_norm.weight"]))
+        self.register_buffer("kn_w", c(sd[a + "k_norm.weight"]))
+        p = "policy_head."
+        self.register_buffer("p_norm", c(sd[p + "norm.weight"]))
+        self.register_buffer("p_gate_w", c(sd[p + "row_gate.weight"].reshape(-1)))
+        self.register_buffer("p_gate_b", f(sd[p + "row_gate.bias"]))
+        self.register_buffer("p_fc_w", c(sd[p + "fc.weight"]))
+        self.register_buffer("p_fc_b", c(sd[p + "fc.bias"]))
+        self.register_buffer("p_out_w", c(sd[p + "out.weight"].reshape(-1)))
+        self.register_buffer("p_out_b", f(sd[p + "out.bias"]))
+        d = "dual_head."
+        self.register_buffer("d_pool_norm", c(sd[d + "pool_norm.weight"]))
+        self.register_buffer("d_pool_w", c(sd[d + "pool_fc.weight"]))
+        self.register_buffer("d_pool_b", c(sd[d + "pool_fc.bias"]))
+        self.register_buffer("d_norm", c(sd[d + "norm.weight"]))
+        self.register_buffer("d_fc_w", c(sd[d + "fc.weight"]))
+        self.register_buffer("d_fc_b", c(sd[d + "fc.bias"]))
+        self.register_buffer("d_out_norm", c(sd[d + "out_norm.weight"]))
+        self.register_buffer("d_val_w", c(sd[d + "value_out.weight"]))
+        self.register_buffer("d_val_b", c(sd[d + "value_out.bias"]))
+        self.register_buffer("d_aux_w", c(sd[d + "aux_out.weight"].reshape(-1)))
+        self.register_buffer("d_aux_b", f(sd[d + "aux_out.bias"]))
+
+    @classmethod
+    def from_module(cls, net, dtype=torch.bfloat16, device=None):
+        sd = net.state_dict()
+        if device is None:
+            device = next(iter(sd.values())).device
+        return cls(sd, device, dtype)
+
+    @staticmethod
+    def recognises(net):
+        need = ("piece_emb", "pos_emb", "hidden", "policy_head", "dual_head", "orbit_map")
+        return all(hasattr(net, n) for n in need)
+
+    # ------------------------------------------------------------------ pieces
+    def _conv(self, tokens, w, b):
+        """3x3 same convolution on (B, 42, Cin) tokens == NHWC image; returns (B, 42, Cout)."""
+        bsz, _, cin = tokens.shape
+        img = tokens.view(bsz, ROWS, COLS, cin).permute(0, 3, 1, 2)          # NCHW view, channels_last strides
+        out = F.conv2d(img, w, b, padding=1)
+        return out.permute(0, 2, 3, 1).reshape(bsz, CELLS, -1)
+
+    def _group_norm1(self, tokens, gamma, beta):
+        bsz = tokens.shape[0]
+        y = F.layer_norm(tokens.reshape(bsz, -1), (tokens.shape[1] * tokens.shape[2],), eps=1e-5)
+        return torch.addcmul(beta, y.view_as(tokens), gamma)
+
+    def _rms(self, x, w):
+        return F.rms_norm(x, (x.shape[-1],), w, 1e-5)
+
+    @torch.no_grad()
+    def forward(self, x, action_mask=None):
+        """x: (B, 3, 6, 7) relative planes (any float dtype).  Returns fp32
+        (log_prob (B,7), value_log_prob (B,3), steps_norm (B,)) like the reference forward."""
+        bsz = x.shape[0]
+        dt = self.dtype
+        own = x[:, 0].reshape(bsz, CELLS, 1).to(dt)
+        opp = x[:, 1].reshape(bsz, CELLS, 1).to(dt)
+        t = torch.addcmul(torch.addcmul(self.pos, own, self.emb_own), opp, self.emb_opp)   # (B, 42, E)
+
+        t = F.silu(self._conv(t, self.stem_w, self.stem_b))
+        for w, b, g, beta in self.res:
+            y = self._group_norm1(t, getattr(self, g), getattr(self, beta))
+            t = t + F.silu(self._conv(y, getattr(self, w), getattr(self, b)))
+
+        # gated attention over the 42 cells
+        h = self._rms(t, self.pre_w)
+        qkvg = F.linear(h, self.qkvg_w)                                       # (B, 42, 3C + heads)
+        c_dim, nh = self.h_dim, self.heads
+        hd = c_dim // nh
+        q, k, v = qkvg[..., :3 * c_dim].view(bsz, CELLS, 3, nh, hd).unbind(2)
+        gate = qkvg[..., 3 * c_dim:]                                          # (B, 42, heads)
+        q = self._rms(q, self.qn_w).transpose(1, 2)
+        k = self._rms(k, self.kn_w).transpose(1, 2)
+        a = F.scaled_dot_product_attention(q, k, v.transpose(1, 2))           # (B, heads, 42, hd)
+        a = a * torch.sigmoid(gate).transpose(1, 2).unsqueeze(-1)
+        t = F.linear(a.transpose(1, 2).reshape(bsz, CELLS, c_dim), self.o_w) + t
+
+        # column policy head
+        pn = self._rms(t, self.p_norm).view(bsz, ROWS, COLS, c_dim)
+        scores = (pn.float() * self.p_gate_w.float()).sum(-1) + self.p_gate_b     # (B, rows, cols)
+        wts = torch.softmax(scores, dim=1).to(dt)                                  # over rows
+        col = (wts.unsqueeze(-1) * pn).sum(dim=1)                                  # (B, cols, C)
+        col = F.silu(F.linear(col, self.p_fc_w, self.p_fc_b))
+        logits = (col.float() * self.p_out_w.float()).sum(-1) + self.p_out_b       # (B, cols)
+        if action_mask is not None:
+            logits = logits.masked_fill(~action_mask.to(torch.bool), -1e9)
+        log_prob = F.log_softmax(logits, dim=-1)
+
+        # value / moves-left head
+        g = t.float().mean(dim=1).to(dt)
+        g = g + F.silu(F.linear(self._rms(g, self.d_pool_norm), self.d_pool_w, self.d_pool_b))
+        hh = self._rms(F.silu(F.linear(self._rms(g, self.d_norm), self.d_fc_w, self.d_fc_b)), self.d_out_norm)
+        value = F.log_softmax(F.linear(hh, self.d_val_w, self.d_val_b).float(), dim=-1)
+        steps = torch.sigmoid((hh.float() * self.d_aux_w.float()).sum(-1) + self.d_aux_b)
+        return log_prob, value, steps
+
+    @torch.no_grad()
+    def predict(self, state, action_mask=None):
+        import numpy as np
+        t = torch.as_tensor(np.asarray(state), dtype=torch.float32, device=self.device)
+        m = None if action_mask is None else torch.as_tensor(np.asarray(action_mask), device=self.device)
+        lp, v, s = self(t, m)
+        return lp.exp().cpu().numpy(), v.exp().cpu().numpy(), (s * 42.0).view(-1, 1).cpu().numpy()

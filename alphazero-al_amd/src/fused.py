@@ -101,6 +101,24 @@ class FusedSearch:
         self._graphs = {}    # (K, vl, cfg key, epoch) -> CUDAGraph
         self._eager_runs = {}
         self.aux_scale = float(getattr(net, "aux_target_offset", 1.0))
+        # inference twin of the reference architecture (fast_net.py); AZ_FUSED_FASTNET=0 calls
+        # the caller's module under autocast exactly as the reference's predict() does
+        self.fast = None
+        self._fast_version = None
+        self.use_fast = os.environ.get("AZ_FUSED_FASTNET", "1") != "0"
+
+    def _sync_fast_net(self):
+        if not self.use_fast or hasattr(self.net, "predict_device"):
+            return
+        from src.fast_net import FastConnect4Net
+        if not FastConnect4Net.recognises(self.net):
+            return
+        version = tuple(p._version for p in self.net.parameters()) + tuple(p.data_ptr() for p in self.net.parameters())
+        if self.fast is None or version != self._fast_version:
+            self.fast = FastConnect4Net.from_module(self.net, device=self.device)
+            self._fast_version = version
+            self._graphs.clear()        # captured graphs hold the old weight buffers
+            self._eager_runs.clear()
 
     # ------------------------------------------------------------------ pieces
     def _buffers(self, K):
@@ -115,6 +133,9 @@ class FusedSearch:
         mask = mask_u8.view(torch.bool) if mask_u8.dtype == torch.uint8 else mask_u8
         if hasattr(self.net, "predict_device"):
             probs, wdl, ml = self.net.predict_device(features, mask)
+        elif self.fast is not None:
+            log_prob, value_lp, steps = self.fast(features, mask)
+            probs, wdl, ml = log_prob.exp(), value_lp.exp(), steps * self.aux_scale
         else:
             with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.autocast):
                 log_prob, value_lp, steps = self.net(features, action_mask=mask)
@@ -176,6 +197,7 @@ class FusedSearch:
         """The reference's iteration schedule (MCTS_cpp.py:110-113, 217-264) on roots that are
         already in HBM."""
         K = max(1, int(vl_batch))
+        self._sync_fast_net()
         check(lib().az_mcts_dev_prepare(self.h, K, int(n_playout)))
         if K <= 1:
             for _ in range(n_playout):

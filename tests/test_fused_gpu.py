@@ -124,6 +124,32 @@ def test_network_port_matches_reference_outputs_g7(env):
     assert np.abs(st.cpu().numpy() - g["ckpt_steps"]).max() < 1e-4
 
 
+def test_fast_inference_twin_g7(env):
+    """fast_net.py computes the reference forward: fp32 build within 1e-4 of the reference's
+    CPU outputs, bf16 build within the same band as the reference's own bf16 autocast."""
+    torch = env["torch"]
+    from src.fast_net import FastConnect4Net
+    g = load("g7_network"); wts = load("g7_checkpoint_weights")
+    net = env["N"].Connect4Net(device="cuda").eval()
+    env["N"].load_reference_weights(net, {k: wts[k] for k in wts.files})
+    planes = _planes(g["boards"], g["turns"]); masks = g["masks"].astype(bool)
+    p, w, ml = FastConnect4Net.from_module(net, dtype=torch.float32).predict(planes, masks)
+    assert np.abs(p - g["ckpt_probs"]).max() < 1e-4 and np.abs(w - g["ckpt_wdl"]).max() < 1e-4
+    assert np.abs(ml - g["ckpt_ml"]).max() < 1e-2
+    p, w, ml = FastConnect4Net.from_module(net).predict(planes, masks)
+    assert np.abs(p - g["ckpt_probs"]).max() < 8e-2 and np.abs(p - g["ckpt_probs"]).mean() < 5e-3
+    assert np.abs(w - g["ckpt_wdl"]).max() < 8e-2 and np.abs(w - g["ckpt_wdl"]).mean() < 5e-3
+    # weight updates on the source module are picked up by the fused path
+    w_ = env["W"].BatchedMCTS(8, 1.4, 100, 0.0, 9, noise_epsilon=0.0, use_symmetry=False)
+    b, t = S.random_openings(np.random.default_rng(1), 8, 4)
+    w_.batch_playout(net, b, t, vl_batch=4)
+    first = w_._fused.fast
+    with torch.no_grad():
+        net.dual_head.value_out.bias.add_(1.0)
+    w_.batch_playout(net, b, t, vl_batch=4)
+    assert w_._fused.fast is not first
+
+
 def test_fused_with_network_statistical_agreement(env):
     """Same network, fused path vs host path: bf16 GEMMs are batch-shape dependent, so compare
     what must hold regardless - simulation budget, probability mass, and near-equal root Q."""
