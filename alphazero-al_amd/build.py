@@ -39,9 +39,9 @@ def _run(cmd):
 def build_engine(force=False):
     os.makedirs(LIB, exist_ok=True)
     out = os.path.join(LIB, "libaz_mcts.so")
-    srcs = [os.path.join(CSRC, f) for f in ("kernels.hip", "engine.hip")]
+    srcs = [os.path.join(CSRC, f) for f in ("kernels.hip", "engine.hip", "nn_kernels.hip")]
     deps = srcs + [os.path.join(CSRC, f) for f in ("kernels.h", "tree_layout.h", "host_rng.h")] + \
-        [os.path.join(INC, "az_mcts.h")]
+        [os.path.join(INC, "az_mcts.h"), os.path.join(INC, "az_nn.h")]
     if force or _stale(out, deps):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         _run([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",

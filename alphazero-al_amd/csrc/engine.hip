@@ -275,8 +275,10 @@ az_mcts *create_engine(int game, int n_envs, int device)
     if (game != AZ_GAME_CONNECT4) throw AzError(AZ_ERR_ARG, "unknown game id");
     if (n_envs <= 0) throw AzError(AZ_ERR_ARG, "n_envs must be positive");
     int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
-        throw AzError(AZ_ERR_DEVICE, "no HIP device available: the search engine runs on the GPU only");
+    const hipError_t dev_err = hipGetDeviceCount(&count);
+    if (dev_err != hipSuccess || count <= 0)
+        throw AzError(AZ_ERR_DEVICE, std::string("no HIP device available: the search engine runs on the GPU only (hipGetDeviceCount: ") +
+                                         hipGetErrorString(dev_err) + ", " + std::to_string(count) + " devices)");
     if (device >= 0) HIP_OK(hipSetDevice(device));
     auto *m = new az_mcts();
     try {

@@ -17,10 +17,36 @@ Statistics of the normalisations and the softmaxes accumulate in fp32 as they do
 reference's bf16 autocast.  `FastConnect4Net.from_module(net)` snapshots any module with the
 reference's parameter names (the reference CNN itself or az_net.Connect4Net).
 """
+import ctypes as C
+import os
+
 import torch
 import torch.nn.functional as F
 
 ROWS, COLS, CELLS = 6, 7, 42
+
+_GLUE = None
+
+
+def glue():
+    """libaz_mcts.so's fused glue kernels (include/az_nn.h), or None when unavailable."""
+    global _GLUE
+    if _GLUE is None:
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lib", "libaz_mcts.so")
+        try:
+            L = C.CDLL(path)
+            vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
+            L.az_nn_embed.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp]
+            L.az_nn_groupnorm1.argtypes = [vp, vp, vp, vp, i64, i32, f32, vp]
+            L.az_nn_silu_add.argtypes = [vp, vp, i32, vp, vp, i64, vp]
+            L.az_nn_rmsnorm64.argtypes = [vp, vp, vp, i64, f32, vp]
+            L.az_nn_qkv_prep.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i64, f32, vp]
+            L.az_nn_attn_post.argtypes = [vp, vp, vp, i64, vp]
+            L.az_nn_heads_prep.argtypes = [vp, vp, vp, f32, vp, vp, i64, f32, vp]
+            _GLUE = L
+        except OSError:
+            _GLUE = False
+    return _GLUE or None
 
 
 class FastConnect4Net(torch.nn.Module):
@@ -58,7 +84,10 @@ class FastConnect4Net(torch.nn.Module):
             i += 1
         a = f"hidden.{i}.attn."
         self.register_buffer("pre_w", c(sd[a + "prenorm.weight"]))
-        self.register_buffer("qkvg_w", c(torch.cat([sd[a + "qkv_proj.weight"], sd[a + "gate_proj.weight"]], 0)))
+        qkvg = torch.cat([sd[a + "qkv_proj.weight"], sd[a + "gate_proj.weight"]], 0)
+        self.register_buffer("qkvg_w", c(qkvg))
+        # the same projection padded to 200 outputs: 400-byte rows keep 16-byte vector alignment
+        self.register_buffer("qkvg_w_pad", c(torch.cat([qkvg, torch.zeros(4, qkvg.shape[1], device=qkvg.device)], 0)))
         self.register_buffer("o_w", c(sd[a + "o_proj.weight"]))
         self.register_buffer("qn_w", c(sd[a + "q_norm.weight"]))
         self.register_buffer("kn_w", c(sd[a + "k_norm.weight"]))
@@ -82,6 +111,11 @@ class FastConnect4Net(torch.nn.Module):
         self.register_buffer("d_val_b", c(sd[d + "value_out.bias"]))
         self.register_buffer("d_aux_w", c(sd[d + "aux_out.weight"].reshape(-1)))
         self.register_buffer("d_aux_b", f(sd[d + "aux_out.bias"]))
+        self.p_gate_b_host = float(sd[p + "row_gate.bias"].reshape(-1)[0].item())
+        # fused HIP glue (nn_kernels.hip) on the GPU with bf16 activations; plain torch otherwise
+        self.hip = (self.device.type == "cuda" and dtype == torch.bfloat16 and self.embed_dim == 32
+                    and self.h_dim == 64 and heads == 4 and os.environ.get("AZ_NN_GLUE", "1") != "0"
+                    and glue() is not None)
 
     @classmethod
     def from_module(cls, net, dtype=torch.bfloat16, device=None):
@@ -111,10 +145,71 @@ class FastConnect4Net(torch.nn.Module):
     def _rms(self, x, w):
         return F.rms_norm(x, (x.shape[-1],), w, 1e-5)
 
+    # ------------------------------------------------------------------ GPU path
+    def _conv_img(self, tokens, w):
+        """bias-free convolution; the bias is applied by the fused SiLU/residual kernel"""
+        bsz, _, cin = tokens.shape
+        img = tokens.view(bsz, ROWS, COLS, cin).permute(0, 3, 1, 2)
+        return F.conv2d(img, w, None, padding=1).permute(0, 2, 3, 1)         # (B, 6, 7, Cout) view
+
+    @torch.no_grad()
+    def _forward_hip(self, x, action_mask):
+        L = glue()
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        bsz = x.shape[0]
+        dev, bf = self.device, torch.bfloat16
+        c_dim = self.h_dim
+        x = x.contiguous().float()
+        t = torch.empty((bsz, CELLS, self.embed_dim), dtype=bf, device=dev)
+        L.az_nn_embed(x.data_ptr(), self.emb_own.data_ptr(), self.emb_opp.data_ptr(), self.pos.data_ptr(),
+                      t.data_ptr(), bsz, self.embed_dim, s)
+        n_el = bsz * CELLS * c_dim
+        conv = self._conv_img(t, self.stem_w).contiguous()
+        t = torch.empty((bsz, CELLS, c_dim), dtype=bf, device=dev)
+        L.az_nn_silu_add(conv.data_ptr(), self.stem_b.data_ptr(), c_dim, None, t.data_ptr(), n_el, s)
+        y = torch.empty_like(t)
+        for w, b, g, beta in self.res:
+            L.az_nn_groupnorm1(t.data_ptr(), getattr(self, g).data_ptr(), getattr(self, beta).data_ptr(),
+                               y.data_ptr(), bsz, c_dim, 1e-5, s)
+            conv = self._conv_img(y, getattr(self, w)).contiguous()
+            t2 = torch.empty_like(t)
+            L.az_nn_silu_add(conv.data_ptr(), getattr(self, b).data_ptr(), c_dim, t.data_ptr(), t2.data_ptr(), n_el, s)
+            t = t2
+        # gated attention
+        rows = bsz * CELLS
+        L.az_nn_rmsnorm64(t.data_ptr(), self.pre_w.data_ptr(), y.data_ptr(), rows, 1e-5, s)
+        qkvg = F.linear(y.view(rows, c_dim), self.qkvg_w_pad)                 # (T, 200)
+        q = torch.empty((bsz, self.heads, CELLS, c_dim // self.heads), dtype=bf, device=dev)
+        k = torch.empty_like(q)
+        v = torch.empty_like(q)
+        gate = torch.empty((rows, self.heads), dtype=bf, device=dev)
+        L.az_nn_qkv_prep(qkvg.data_ptr(), 200, self.qn_w.data_ptr(), self.kn_w.data_ptr(), q.data_ptr(),
+                         k.data_ptr(), v.data_ptr(), gate.data_ptr(), bsz, 1e-5, s)
+        a = F.scaled_dot_product_attention(q, k, v).contiguous()
+        L.az_nn_attn_post(a.data_ptr(), gate.data_ptr(), y.data_ptr(), bsz, s)
+        t = torch.addmm(t.view(rows, c_dim), y.view(rows, c_dim), self.o_w.t()).view(bsz, CELLS, c_dim)
+        # heads
+        col = torch.empty((bsz, COLS, c_dim), dtype=bf, device=dev)
+        mean = torch.empty((bsz, c_dim), dtype=bf, device=dev)
+        L.az_nn_heads_prep(t.data_ptr(), self.p_norm.data_ptr(), self.p_gate_w.data_ptr(), self.p_gate_b_host,
+                           col.data_ptr(), mean.data_ptr(), bsz, 1e-5, s)
+        col = F.silu(F.linear(col, self.p_fc_w, self.p_fc_b))
+        logits = (col.float() * self.p_out_w.float()).sum(-1) + self.p_out_b
+        if action_mask is not None:
+            logits = logits.masked_fill(~action_mask.to(torch.bool), -1e9)
+        log_prob = F.log_softmax(logits, dim=-1)
+        g = mean + F.silu(F.linear(self._rms(mean, self.d_pool_norm), self.d_pool_w, self.d_pool_b))
+        hh = self._rms(F.silu(F.linear(self._rms(g, self.d_norm), self.d_fc_w, self.d_fc_b)), self.d_out_norm)
+        value = F.log_softmax(F.linear(hh, self.d_val_w, self.d_val_b).float(), dim=-1)
+        steps = torch.sigmoid((hh.float() * self.d_aux_w.float()).sum(-1) + self.d_aux_b)
+        return log_prob, value, steps
+
     @torch.no_grad()
     def forward(self, x, action_mask=None):
         """x: (B, 3, 6, 7) relative planes (any float dtype).  Returns fp32
         (log_prob (B,7), value_log_prob (B,3), steps_norm (B,)) like the reference forward."""
+        if self.hip and x.is_cuda:
+            return self._forward_hip(x, action_mask)
         bsz = x.shape[0]
         dt = self.dtype
         own = x[:, 0].reshape(bsz, CELLS, 1).to(dt)

@@ -1,0 +1,51 @@
+/*
+ * az_nn.h - C ABI of the fused "glue" kernels of the leaf evaluator (part of libaz_mcts.so).
+ *
+ * These do not replace a reference FFI entry point: the reference's evaluator is a PyTorch
+ * module (src/environments/Connect4/Network.py) and stays one here.  They replace, inside our
+ * inference twin of that module (alphazero-al_amd/src/fast_net.py), the chains of small
+ * PyTorch kernels between its GEMM-shaped operations.  All tensors are DEVICE pointers to
+ * contiguous bf16 data in token layout (batch, 42, channels) unless stated; `stream` is a
+ * hipStream_t; every function only enqueues work and returns 0, or 1 on a bad argument.
+ */
+#ifndef AZ_NN_H
+#define AZ_NN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* tokens[b, cell, :] = pos[cell, :] + own(b, cell) * emb_own + opp(b, cell) * emb_opp
+ * (Network.py:226-239).  features: float32 (batch, 3, 6, 7) relative planes; embed_dim 32. */
+int az_nn_embed(const float *features, const void *emb_own, const void *emb_opp, const void *pos,
+                void *tokens, int64_t batch, int embed_dim, void *stream);
+/* GroupNorm(num_groups=1) over each sample's 42*channels values + per-channel affine
+ * (Network.py:38,44); channels 64. */
+int az_nn_groupnorm1(const void *x, const void *gamma, const void *beta, void *y, int64_t batch,
+                     int channels, float eps, void *stream);
+/* y = residual + silu(x + bias[channel]) - convolution bias, SiLU and skip connection in one
+ * pass (Network.py:44-48).  bias (channels values, channel = fastest dimension of x) and
+ * residual may be NULL; n_elements and channels multiples of 8. */
+int az_nn_silu_add(const void *x, const void *bias, int channels, const void *residual, void *y,
+                   int64_t n_elements, void *stream);
+/* nn.RMSNorm over the last dimension of 64 */
+int az_nn_rmsnorm64(const void *x, const void *w, void *y, int64_t rows, float eps, void *stream);
+/* qkvg (batch*42, row_len) with row_len 196 or 200 (3*64 q|k|v, 4 gate logits, optional zero
+ * pad) -> q, k, v (batch, 4, 42, 16) with per-head RMSNorm on q and k, and sigmoid(gate)
+ * (batch*42, 4) (Network.py:66-71,80). */
+int az_nn_qkv_prep(const void *qkvg, int row_len, const void *q_norm_w, const void *k_norm_w, void *q,
+                   void *k, void *v, void *gate_sigmoid, int64_t batch, float eps, void *stream);
+/* out[tok, h*16+d] = attn[b, h, t, d] * gate_sigmoid[tok, h] (Network.py:80-82) */
+int az_nn_attn_post(const void *attn, const void *gate_sigmoid, void *out, int64_t batch, void *stream);
+/* policy-head pooling and value-head mean of one pass over the final tokens (batch, 42, 64):
+ * col (batch, 7, 64) = softmax-over-rows weighted sum of the RMS-normalised tokens of each
+ * column, mean (batch, 64) = plain token mean (Network.py:107-113,135). */
+int az_nn_heads_prep(const void *tokens, const void *p_norm_w, const void *p_gate_w, float p_gate_b,
+                     void *col, void *mean, int64_t batch, float eps, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -150,6 +150,92 @@ def test_fast_inference_twin_g7(env):
     assert w_._fused.fast is not first
 
 
+def test_glue_kernels_match_torch(env):
+    """nn_kernels.hip against the torch ops they replace (same bf16 inputs, fp32 maths)."""
+    torch = env["torch"]
+    import ctypes as C
+    import torch.nn.functional as TF
+    from src.fast_net import glue
+    L = glue()
+    assert L is not None
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device="cuda"); g.manual_seed(0)
+    bf = torch.bfloat16
+    B = 333
+    rnd = lambda *sh: torch.randn(*sh, device="cuda", generator=g)    # noqa: E731
+
+    def close(a, b, tol=2e-2):
+        d = (a.float() - b.float()).abs().max().item()
+        assert d < tol, d
+
+    # embed
+    feats = (torch.rand(B, 3, 6, 7, device="cuda", generator=g) > 0.6).float()
+    eo, ep, pos = rnd(32).to(bf), rnd(32).to(bf), rnd(42, 32).to(bf)
+    tok = torch.empty(B, 42, 32, dtype=bf, device="cuda")
+    L.az_nn_embed(feats.data_ptr(), eo.data_ptr(), ep.data_ptr(), pos.data_ptr(), tok.data_ptr(), B, 32, s)
+    want = pos.float() + feats[:, 0].reshape(B, 42, 1) * eo.float() + feats[:, 1].reshape(B, 42, 1) * ep.float()
+    close(tok, want)
+    # groupnorm1 + affine
+    x = (rnd(B, 42, 64) * 2 + 0.5).to(bf); ga, be = rnd(64).to(bf), rnd(64).to(bf)
+    y = torch.empty_like(x)
+    L.az_nn_groupnorm1(x.data_ptr(), ga.data_ptr(), be.data_ptr(), y.data_ptr(), B, 64, 1e-5, s)
+    want = TF.group_norm(x.float().permute(0, 2, 1).reshape(B, 64, 6, 7), 1, ga.float(), be.float(), 1e-5)
+    close(y, want.reshape(B, 64, 42).permute(0, 2, 1), 4e-2)
+    # silu + bias + residual
+    r = rnd(B, 42, 64).to(bf); bias = rnd(64).to(bf)
+    L.az_nn_silu_add(x.data_ptr(), bias.data_ptr(), 64, r.data_ptr(), y.data_ptr(), x.numel(), s)
+    close(y, r.float() + TF.silu((x.float() + bias.float()).to(bf).float()), 4e-2)
+    L.az_nn_silu_add(x.data_ptr(), None, 0, None, y.data_ptr(), x.numel(), s)
+    close(y, TF.silu(x.float()), 4e-2)
+    # rmsnorm64
+    w = rnd(64).to(bf)
+    L.az_nn_rmsnorm64(x.data_ptr(), w.data_ptr(), y.data_ptr(), B * 42, 1e-5, s)
+    close(y, TF.rms_norm(x.float(), (64,), w.float(), 1e-5), 4e-2)
+    # qkv prep (both row lengths) and attention post
+    for row_len in (196, 200):
+        qkvg = rnd(B * 42, row_len).to(bf); qn, kn = rnd(16).to(bf), rnd(16).to(bf)
+        q = torch.empty(B, 4, 42, 16, dtype=bf, device="cuda"); k = torch.empty_like(q); v = torch.empty_like(q)
+        gate = torch.empty(B * 42, 4, dtype=bf, device="cuda")
+        L.az_nn_qkv_prep(qkvg.data_ptr(), row_len, qn.data_ptr(), kn.data_ptr(), q.data_ptr(), k.data_ptr(),
+                         v.data_ptr(), gate.data_ptr(), B, 1e-5, s)
+        parts = qkvg[:, :192].float().view(B, 42, 3, 4, 16)
+        close(q, TF.rms_norm(parts[:, :, 0], (16,), qn.float(), 1e-5).transpose(1, 2), 4e-2)
+        close(k, TF.rms_norm(parts[:, :, 1], (16,), kn.float(), 1e-5).transpose(1, 2), 4e-2)
+        close(v, parts[:, :, 2].transpose(1, 2), 1e-6)
+        close(gate, torch.sigmoid(qkvg[:, 192:196].float()))
+    out = torch.empty(B * 42, 64, dtype=bf, device="cuda")
+    L.az_nn_attn_post(q.data_ptr(), gate.data_ptr(), out.data_ptr(), B, s)
+    want = (q.float() * gate.float().view(B, 42, 4).transpose(1, 2).unsqueeze(-1)).transpose(1, 2).reshape(B * 42, 64)
+    close(out, want, 4e-2)
+    # head pooling
+    pw, gw = rnd(64).to(bf), (rnd(64) * 0.3).to(bf)
+    col = torch.empty(B, 7, 64, dtype=bf, device="cuda"); mean = torch.empty(B, 64, dtype=bf, device="cuda")
+    L.az_nn_heads_prep(x.data_ptr(), pw.data_ptr(), gw.data_ptr(), 0.25, col.data_ptr(), mean.data_ptr(), B, 1e-5, s)
+    pn = TF.rms_norm(x.float(), (64,), pw.float(), 1e-5).to(bf).float().view(B, 6, 7, 64)
+    sc = (pn * gw.float()).sum(-1) + 0.25
+    wts = torch.softmax(sc, dim=1)
+    close(col, (wts.unsqueeze(-1) * pn).sum(1), 6e-2)
+    close(mean, x.float().mean(1), 2e-2)
+    torch.cuda.synchronize()
+
+
+def test_fast_net_hip_path_equals_torch_path(env):
+    torch = env["torch"]
+    from src.fast_net import FastConnect4Net
+    g = load("g7_network"); wts = load("g7_checkpoint_weights")
+    net = env["N"].Connect4Net(device="cuda").eval()
+    env["N"].load_reference_weights(net, {k: wts[k] for k in wts.files})
+    planes = _planes(g["boards"], g["turns"]); masks = g["masks"].astype(bool)
+    fast = FastConnect4Net.from_module(net)
+    assert fast.hip
+    p1, w1, m1 = fast.predict(planes, masks)
+    fast.hip = False
+    p2, w2, m2 = fast.predict(planes, masks)
+    assert np.abs(p1 - p2).max() < 5e-2 and np.abs(w1 - w2).max() < 5e-2 and np.abs(m1 - m2).max() < 2.0
+    assert np.abs(p1 - g["ckpt_probs"]).max() < 8e-2 and np.abs(p1 - g["ckpt_probs"]).mean() < 5e-3
+    assert np.abs(w1 - g["ckpt_wdl"]).max() < 8e-2 and np.abs(w1 - g["ckpt_wdl"]).mean() < 5e-3
+
+
 def test_fused_with_network_statistical_agreement(env):
     """Same network, fused path vs host path: bf16 GEMMs are batch-shape dependent, so compare
     what must hold regardless - simulation budget, probability mass, and near-equal root Q."""
