@@ -18,6 +18,14 @@ from collections import OrderedDict
 
 import numpy as np
 
+try:
+    # PyTorch-ROCm wheels bundle their own libamdhip64; importing torch FIRST makes the engine
+    # library bind to that same HIP runtime (one runtime per process: shared streams and
+    # ordering with the network's kernels).  Without torch the system ROCm runtime is used.
+    import torch  # noqa: F401
+except ImportError:      # the search engine itself does not need torch
+    pass
+
 from src import mcts_cpp
 
 # game name -> native class (MCTS_cpp.py:9-12)

@@ -54,6 +54,25 @@ def lib():
     return _LIB
 
 
+def hip_runtimes_loaded():
+    """Paths of the libamdhip64 images mapped into this process."""
+    try:
+        with open("/proc/self/maps") as f:
+            return sorted({ln.split()[-1] for ln in f if "libamdhip64" in ln})
+    except OSError:
+        return []
+
+
+def require_single_hip_runtime():
+    """The fused loop shares streams between PyTorch and the engine, which is only meaningful
+    inside ONE HIP runtime.  Two get loaded when the engine library is imported before torch
+    (torch then brings its bundled copy): fail loudly instead of racing."""
+    libs = hip_runtimes_loaded()
+    if len(libs) > 1:
+        raise RuntimeError("two HIP runtimes are loaded (%s): import torch before src.mcts_cpp / "
+                           "src.MCTS_cpp so that the engine binds to torch's runtime" % ", ".join(libs))
+
+
 def check(rc):
     if rc != 0:
         raise RuntimeError(lib().az_last_error().decode())
@@ -86,6 +105,7 @@ class FusedSearch:
     """One instance per (BatchedMCTS wrapper, network) pair."""
 
     def __init__(self, wrapper, net):
+        require_single_hip_runtime()
         self.w = wrapper
         self.net = net
         self.h = C.c_void_p(wrapper.mcts.handle)

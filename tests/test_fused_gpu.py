@@ -23,6 +23,7 @@ PKG = os.path.join(ROOT, "alphazero-al_amd")
 @pytest.fixture(scope="module")
 def env():
     sys.path.insert(0, ROOT)
+    import torch  # noqa: F401  (before the engine library: one HIP runtime per process)
     import __graft_entry__ as ge
     ge.build()
     if PKG not in sys.path:
