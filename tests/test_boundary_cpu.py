@@ -56,10 +56,13 @@ def have_gpu():
 
 
 def test_c_abi_exports_every_declared_symbol(built):
-    hdr = open(os.path.join(ROOT, "include", "az_mcts.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    names = set(re.findall(r"\b(az_[a-z0-9_]+)\s*\(", hdr))
-    assert len(names) >= 30
+    names = set()
+    inc = os.path.join(ROOT, "include")
+    for fn in sorted(os.listdir(inc)):
+        if fn.endswith(".h"):
+            hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(inc, fn)).read(), flags=re.S)
+            names |= set(re.findall(r"\b(az_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 45
     lib = C.CDLL(os.path.join(PKG, "lib", "libaz_mcts.so"))
     missing = [n for n in sorted(names) if not hasattr(lib, n)]
     assert not missing, missing
