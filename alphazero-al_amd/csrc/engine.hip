@@ -599,10 +599,48 @@ int az_mcts_backprop_batch_vl(az_mcts *m, int K, const float *policy, const floa
     });
 }
 
-int az_mcts_search_rollout(az_mcts *, const int8_t *, const int32_t *, int64_t, int)
+int az_mcts_search_rollout(az_mcts *m, const int8_t *boards, const int32_t *turns, int64_t n, int n_playout)
 {
-    g_last_error = "search with RolloutEvaluator is not implemented on the device yet";
-    return AZ_ERR_STATE;
+    // BatchedMCTS::search (BatchedMCTS.h:339-407): n_playout x { simulate, evaluate the
+    // non-terminal leaves by random playout, backprop } with no symmetry and no virtual loss,
+    // the whole loop on the device.  Playout moves and root noise use the device generator
+    // (the reference draws them from per-thread engines, so its stream is thread-count
+    // dependent anyway).
+    return guarded([&] {
+        require(n == m->B, "search: input_boards batch size (" + std::to_string(n) + ") must match n_envs (" +
+                               std::to_string(m->B) + ")");
+        require(n_playout >= 0, "search: n_playout must be >= 0");
+        HIP_OK(hipSetDevice(m->device));
+        const int B = m->B;
+        hipStream_t s = nullptr;
+        m->flush_resets(s);
+        m->io_boards_in.ensure(static_cast<size_t>(B) * CELLS);
+        m->io_turns_in.ensure(B);
+        HIP_OK(hipMemcpy(m->io_boards_in.p, boards, static_cast<size_t>(B) * CELLS, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(m->io_turns_in.p, turns, sizeof(int32_t) * B, hipMemcpyHostToDevice));
+        az::launch_import(m->io_boards_in.p, m->io_turns_in.p, m->roots(), B, s);
+        m->plain_leaf.ensure(B);
+        HIP_OK(hipMemset(m->plain_leaf.sym.p, 0, sizeof(int32_t) * B));
+        m->io_policy.ensure(static_cast<size_t>(B) * A); m->io_d.ensure(B); m->io_p1.ensure(B);
+        m->io_p2.ensure(B); m->io_ml.ensure(B); m->io_is_term.ensure(B);
+        m->ensure_room(static_cast<int64_t>(n_playout) * A);
+        const az::SearchParams p = m->params();
+        az::EvalIn in{};
+        in.policy = m->io_policy.p; in.d = m->io_d.p; in.p1w = m->io_p1.p; in.p2w = m->io_p2.p;
+        in.is_term = m->io_is_term.p; in.moves_left = m->io_ml.p; in.sym = nullptr; in.root_noise = nullptr;
+        m->last_select_vl = false;
+        for (int it = 0; it < n_playout; ++it) {
+            az::launch_select(m->arena(), m->roots(), m->plain_leaf.view(), p, 1, false, m->counters.p, s);
+            az::launch_rollout(m->plain_leaf.view(), p, B, m->io_policy.p, m->io_d.p, m->io_p1.p, m->io_p2.p,
+                               m->io_ml.p, m->io_is_term.p, s);
+            az::launch_backprop(m->arena(), m->plain_leaf.view(), p, 1, false, false, in, m->counters.p, m->err.p, s);
+            az::launch_bump_call(m->call_ctr.p, s);
+        }
+        m->select_launches += n_playout;
+        m->backprop_launches += n_playout;
+        HIP_OK(hipStreamSynchronize(s));
+        m->check_device_error();
+    });
 }
 
 int az_mcts_get_all_counts(az_mcts *m, int32_t *out)

@@ -93,6 +93,8 @@ void launch_reset_masked(TreeArena ar, const uint8_t *mask, hipStream_t s);
 void launch_counts(TreeArena ar, int32_t *counts, hipStream_t s);
 void launch_root_stats(TreeArena ar, float *stats, hipStream_t s);
 void launch_init_trees(TreeArena ar, hipStream_t s);
+void launch_rollout(LeafBuf lf, SearchParams p, int B, float *policy, float *d, float *p1w, float *p2w, float *ml,
+                    uint8_t *is_term, hipStream_t s);
 void launch_c4_step(uint64_t *bb0, uint64_t *bb1, int32_t *turns, const int32_t *actions,
                     uint8_t *done, int32_t *winner, int64_t n, bool reset_finished, hipStream_t s);
 

@@ -768,6 +768,53 @@ __global__ void __launch_bounds__(WAVE) k_root_query(TreeArena ar, int32_t *coun
     }
 }
 
+// ------------------------------------------------------------------ random-playout evaluator
+
+// RolloutEvaluator::evaluate_single (RolloutEvaluator.h:23-48) for the leaves of one plain
+// selection: uniform policy (all ones), value = result of a uniformly random playout from
+// the leaf, moves_left 0.  One thread per tree; moves come from the device generator.
+__global__ void __launch_bounds__(256) k_rollout(LeafBuf lf, SearchParams p, int B, float *policy, float *d,
+                                                 float *p1w, float *p2w, float *ml, uint8_t *is_term)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B) return;
+    const uint8_t fl = lf.flags[t];
+    const bool term = (fl & LEAF_TERMINAL) != 0;
+    int code = (fl >> LEAF_RESULT_SHIFT) & 3;
+    if (!term) {
+        uint64_t bb0 = lf.bb0[t], bb1 = lf.bb1[t];
+        int turn = lf.turn[t];
+        // last mover of the leaf position: parity of the piece count, as import_board derives it
+        const int pieces = __popcll(bb0 | bb1);
+        int last = pieces == 0 ? -1 : ((pieces & 1) ? 0 : 1);
+        DevRng g(p.seed, *p.call_ptr, static_cast<uint64_t>(t), 3);
+        int res = c4_result(bb0, bb1, last);
+        while (res < 0) {
+            const uint64_t occ = bb0 | bb1;
+            int cols[C4_COLS], nv = 0;
+#pragma unroll
+            for (int c = 0; c < C4_COLS; ++c)
+                if (!((occ >> (c * C4_BITS_PER_COL + C4_ROWS - 1)) & 1ull)) cols[nv++] = c;
+            const int a = cols[static_cast<int>((static_cast<uint64_t>(g.next()) * static_cast<uint64_t>(nv)) >> 32)];
+            const uint64_t colmask = 0x7Full << (C4_BITS_PER_COL * a);
+            const uint64_t mv = ((occ & colmask) + (1ull << (C4_BITS_PER_COL * a))) & colmask;
+            const int mover = (turn == 1) ? 0 : 1;
+            if (mover == 0) bb0 |= mv; else bb1 |= mv;
+            last = mover;
+            turn = -turn;
+            res = c4_result(bb0, bb1, last);
+        }
+        code = res;
+    }
+    is_term[t] = term ? 1 : 0;
+    d[t] = code == 0 ? 1.0f : 0.0f;
+    p1w[t] = code == 1 ? 1.0f : 0.0f;
+    p2w[t] = code == 2 ? 1.0f : 0.0f;
+    ml[t] = 0.0f;
+#pragma unroll
+    for (int a = 0; a < C4_ACTIONS; ++a) policy[static_cast<size_t>(t) * C4_ACTIONS + a] = term ? 0.0f : 1.0f;
+}
+
 // ------------------------------------------------------------------ batched game step
 
 // Connect4.h:159-172 (step) + 182-203 / 221-224 (result) on HBM-resident positions
@@ -876,6 +923,12 @@ void launch_root_stats(TreeArena ar, float *stats, hipStream_t s)
 {
     hipLaunchKernelGGL(k_root_query<true>, dim3(groups_grid(ar.B)), dim3(WAVE), 0, s, ar,
                        static_cast<int32_t *>(nullptr), stats);
+}
+
+void launch_rollout(LeafBuf lf, SearchParams p, int B, float *policy, float *d, float *p1w, float *p2w, float *ml,
+                    uint8_t *is_term, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_rollout, dim3((B + 255) / 256), dim3(256), 0, s, lf, p, B, policy, d, p1w, p2w, ml, is_term);
 }
 
 void launch_c4_step(uint64_t *bb0, uint64_t *bb1, int32_t *turns, const int32_t *actions,

@@ -197,14 +197,10 @@ def main():
     games = tot["games"] - t_before["games"]
 
     # one collective: sum the counters, max the time (xGMI, a few dozen bytes)
-    vec = torch.tensor([positions, cnt["sims"], cnt["expansions"], games, cnt["levels"], cnt["backup_nodes"]],
-                       dtype=torch.int64, device=dev)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    g_pos, g_sims, g_exp, g_games, g_levels, g_backup = [int(v) for v in vec.tolist()]
-    t = float(tmax.item())
+    from src.shard import reduce_counters
+    totals, t = reduce_counters([positions, cnt["sims"], cnt["expansions"], games, cnt["levels"],
+                                 cnt["backup_nodes"]], elapsed, dev)
+    g_pos, g_sims, g_exp, g_games = totals["positions"], totals["sims"], totals["expansions"], totals["games"]
 
     if rank == 0:
         sims_rank = max(cnt["sims"], 1)

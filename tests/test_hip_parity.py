@@ -194,3 +194,34 @@ def test_raw_c_abi_via_ctypes(mcts_cpp):
     assert L.az_mcts_search_batch(h, raw.p(boards), raw.p(turns), C.c_int64(3), *([None] * 7)) == 1
     assert b"n_envs" in L.az_last_error()
     L.az_mcts_destroy(h)
+
+
+def test_rollout_search_on_device(mcts_cpp):
+    """a27: BatchedMCTS::search with RolloutEvaluator.  Playout moves come from the device
+    generator, so the comparison with the (bit-exact) oracle is statistical; what is exact:
+    the simulation budget, and forced lines."""
+    from src import MCTS_cpp
+    rng = np.random.default_rng(21)
+    boards, turns = S.random_openings(rng, 256, 10)
+    # tree 0: P1 to move with three in a row on the bottom -> col 3 wins at once
+    boards[0] = 0; boards[0, 5, 0:3] = 1; boards[0, 4, 0:3] = -1; turns[0] = 1
+    w = MCTS_cpp.BatchedMCTS(256, c_init=4, c_base=500, alpha=0, n_playout=300, noise_epsilon=0.0,
+                             fpu_reduction=0.0, use_symmetry=False)               # player.py:84-88
+    w.seed(3)
+    w.rollout_playout(boards, turns)
+    c = w.get_visits_count()
+    st = w.get_root_stats()
+    assert (st["root_N"] == 300).all() and (c.sum(1) == 299).all()
+    assert c[0].argmax() == 3 and st["P1W"][0, 3] == 1.0
+    assert np.allclose(st["root_D"] + st["root_P1W"] + st["root_P2W"], 1.0, atol=1e-5)
+    # against the oracle (its own mt19937 stream): mean root value and the most visited move agree
+    o = O.BatchedMCTS_Connect4(256)
+    S.apply_cfg(o, dict(c_init=4.0, c_base=500.0, dirichlet_alpha=0.0, noise_epsilon=0.0, fpu_reduction=0.0,
+                        use_symmetry=False, mlh_slope=0.0, mlh_cap=0.2, value_decay=1.0))
+    o.set_seed(3)
+    o.search_rollout(boards, turns, 300)
+    so = o.get_all_root_stats()
+    assert abs(float(st["root_Q"].mean()) - float(so[:, 1].mean())) < 0.03
+    co = S.counts_of(o, 256)
+    assert (c.argmax(1) == co.argmax(1)).mean() > 0.6
+    assert np.abs(c / 299.0 - co / 299.0).mean() < 0.06
