@@ -21,6 +21,8 @@
 // decay - see oracle/mcts_oracle.c) are explicit fmaf().  No MFMA: this is index/bit work.
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace az {
 namespace {
 
@@ -166,13 +168,13 @@ __global__ void __launch_bounds__(256) k_set_roots(const uint64_t *bb0, const ui
 // with compute_fpu (140-156) and select_edge (163-234) evaluated across the group's lanes.
 template <bool VL>
 __global__ void __launch_bounds__(WAVE) k_select(TreeArena ar, RootState rs, LeafBuf lf,
-                                                 SearchParams p, int K,
+                                                 SearchParams p, int K, int tpw,
                                                  unsigned long long *counters)
 {
     const int lane = threadIdx.x;
     const int sub = lane & (G - 1);
-    const int tree = blockIdx.x * TREES_PER_WAVE + (lane >> 3);
-    const bool live = tree < ar.B;
+    const int tree = blockIdx.x * tpw + (lane >> 3);
+    const bool live = (lane >> 3) < tpw && tree < ar.B;
     const int t = live ? tree : 0;
 
     HotRec *hot = ar.hot + static_cast<size_t>(t) * ar.S;
@@ -393,13 +395,13 @@ __global__ void __launch_bounds__(WAVE) k_remove_vl(TreeArena ar, LeafBuf lf, Se
 // FUSED=true takes the evaluator's raw outputs (relative WDL) and the leaf's own flags, i.e.
 // it also does what MCTS_cpp.py:275-297 does between the two native calls.
 template <bool VL, bool FUSED>
-__global__ void __launch_bounds__(WAVE) k_backprop(TreeArena ar, LeafBuf lf, SearchParams p, int K,
+__global__ void __launch_bounds__(WAVE) k_backprop(TreeArena ar, LeafBuf lf, SearchParams p, int K, int tpw,
                                                    EvalIn in, unsigned long long *counters, int *err)
 {
     const int lane = threadIdx.x;
     const int sub = lane & (G - 1);
-    const int tree = blockIdx.x * TREES_PER_WAVE + (lane >> 3);
-    const bool live = tree < ar.B;
+    const int tree = blockIdx.x * tpw + (lane >> 3);
+    const bool live = (lane >> 3) < tpw && tree < ar.B;
     const int t = live ? tree : 0;
     HotRec *hot = ar.hot + static_cast<size_t>(t) * ar.S;
     ColdRec *cold = ar.cold + static_cast<size_t>(t) * ar.S;
@@ -865,22 +867,39 @@ void launch_bump_call(uint64_t *call_ctr, hipStream_t s)
     hipLaunchKernelGGL(k_bump_call, dim3(1), dim3(1), 0, s, call_ctr);
 }
 
+// Trees per wavefront for the two heavy kernels (AZ_TREES_PER_WAVE, default 8 = all lanes
+// busy).  Measured on MI355X at 8192 trees, K=4 (hash evaluator): 8 -> 75.6 us per selection
+// launch, 4 -> 96.4, 2 -> 142.4, 1 -> 236.5: the kernels are bound by instruction issue and
+// dependent-instruction latency, not by memory latency, so spreading the trees over more
+// wavefronts only multiplies the instruction count.
+int trees_per_wave()
+{
+    static const int v = [] {
+        const char *e = getenv("AZ_TREES_PER_WAVE");
+        int t = e ? atoi(e) : 8;
+        return (t == 1 || t == 2 || t == 4 || t == 8) ? t : 8;
+    }();
+    return v;
+}
+
 void launch_select(TreeArena ar, RootState rs, LeafBuf lf, SearchParams p, int K, bool vl,
                    unsigned long long *counters, hipStream_t s)
 {
-    const dim3 grid(groups_grid(ar.B)), block(WAVE);
-    if (vl) hipLaunchKernelGGL(k_select<true>, grid, block, 0, s, ar, rs, lf, p, K, counters);
-    else    hipLaunchKernelGGL(k_select<false>, grid, block, 0, s, ar, rs, lf, p, K, counters);
+    const int tpw = trees_per_wave();
+    const dim3 grid((ar.B + tpw - 1) / tpw), block(WAVE);
+    if (vl) hipLaunchKernelGGL(k_select<true>, grid, block, 0, s, ar, rs, lf, p, K, tpw, counters);
+    else    hipLaunchKernelGGL(k_select<false>, grid, block, 0, s, ar, rs, lf, p, K, tpw, counters);
 }
 
 void launch_backprop(TreeArena ar, LeafBuf lf, SearchParams p, int K, bool vl, bool fused,
                      EvalIn in, unsigned long long *counters, int *err, hipStream_t s)
 {
-    const dim3 grid(groups_grid(ar.B)), block(WAVE);
-    if (vl && fused)        hipLaunchKernelGGL((k_backprop<true, true>), grid, block, 0, s, ar, lf, p, K, in, counters, err);
-    else if (vl && !fused)  hipLaunchKernelGGL((k_backprop<true, false>), grid, block, 0, s, ar, lf, p, K, in, counters, err);
-    else if (!vl && fused)  hipLaunchKernelGGL((k_backprop<false, true>), grid, block, 0, s, ar, lf, p, K, in, counters, err);
-    else                    hipLaunchKernelGGL((k_backprop<false, false>), grid, block, 0, s, ar, lf, p, K, in, counters, err);
+    const int tpw = trees_per_wave();
+    const dim3 grid((ar.B + tpw - 1) / tpw), block(WAVE);
+    if (vl && fused)        hipLaunchKernelGGL((k_backprop<true, true>), grid, block, 0, s, ar, lf, p, K, tpw, in, counters, err);
+    else if (vl && !fused)  hipLaunchKernelGGL((k_backprop<true, false>), grid, block, 0, s, ar, lf, p, K, tpw, in, counters, err);
+    else if (!vl && fused)  hipLaunchKernelGGL((k_backprop<false, true>), grid, block, 0, s, ar, lf, p, K, tpw, in, counters, err);
+    else                    hipLaunchKernelGGL((k_backprop<false, false>), grid, block, 0, s, ar, lf, p, K, tpw, in, counters, err);
 }
 
 void launch_remove_vl(TreeArena ar, LeafBuf lf, SearchParams p, int K, int strideK, hipStream_t s)

@@ -212,7 +212,7 @@ def test_rollout_search_on_device(mcts_cpp):
     c = w.get_visits_count()
     st = w.get_root_stats()
     assert (st["root_N"] == 300).all() and (c.sum(1) == 299).all()
-    assert c[0].argmax() == 3 and st["P1W"][0, 3] == 1.0
+    assert c[0].argmax() == 3 and st["P1W"][0, 3] > 0.9999
     assert np.allclose(st["root_D"] + st["root_P1W"] + st["root_P2W"], 1.0, atol=1e-5)
     # against the oracle (its own mt19937 stream): mean root value and the most visited move agree
     o = O.BatchedMCTS_Connect4(256)
