@@ -11,6 +11,8 @@
  *   src/cpp/MCTS.h          single-tree PUCT + virtual loss   -> mcts_oracle.c
  *   src/cpp/BatchedMCTS.h   per-env batch layer (serial here) -> mcts_oracle.c
  *   src/cpp/RolloutEvaluator.h random playout evaluator       -> mcts_oracle.c
+ *   src/cpp/Othello.h       bitboard game + its search        -> othello_oracle.c
+ *   (mcts_impl.inc is the game-generic body both searches are compiled from)
  *   libstdc++-11 <random>   mt19937 / uniform_int / gamma     -> rng_oracle.c
  *
  * Parity pin: checked bit-for-bit against the real reference compiled into oracle/_ref
@@ -81,6 +83,31 @@ void orc_c4_mirror(orc_c4 *s, int sym_id);         /* apply_symmetry            
 /* env_common.h:93-119 make_current_state -> float[3*42] */
 void orc_c4_current_state(orc_c4 *s, float *out126);
 
+/* ---------------------------------------------------------------- othello_oracle.c */
+
+enum { ORO_OT_CELLS = 64, ORO_OT_ACTIONS = 65, ORO_OT_PASS = 64 };
+
+typedef struct {
+    int8_t   cells[ORO_OT_CELLS]; /* display grid (Othello.h:51)                       */
+    int      turn;
+    uint64_t bb[2];               /* bit i = row i/8, col i%8                          */
+    int      n_pieces;
+    int      passes;              /* consecutive passes since import (Othello.h:56)    */
+    int      last_player;
+} oro_ot;
+
+void     oro_ot_reset(oro_ot *s);
+void     oro_ot_import(oro_ot *s, const int8_t *cells64);
+void     oro_ot_export_cells(oro_ot *s);
+void     oro_ot_step(oro_ot *s, int action);
+int      oro_ot_winner(const oro_ot *s);
+int      oro_ot_full(const oro_ot *s);            /* == is_game_over                    */
+uint64_t oro_ot_valid_positions(const oro_ot *s);
+int      oro_ot_valid_moves(const oro_ot *s, int *moves65);
+void     oro_ot_apply_sym(oro_ot *s, int sym_id);
+void     oro_ot_transform_coord(int sym, int r, int c, int *nr, int *nc);
+void     oro_ot_current_state(oro_ot *s, float *out192);
+
 /* ---------------------------------------------------------------- mcts_oracle.c */
 
 typedef struct {
@@ -141,6 +168,36 @@ void orc_stats_get(const orc_batch *b, orc_stats *out);
 void orc_stats_reset(orc_batch *b);
 /* pool occupancy of one tree: nodes / edges in use */
 void orc_tree_size(const orc_batch *b, int env, int32_t *nodes, int32_t *edges);
+
+/* The same search instantiated for Othello (othello_oracle.c): identical signatures, boards
+ * of 64 cells, 65 actions, 526 statistics per tree. */
+typedef struct oro_batch oro_batch;
+oro_batch  *oro_create(int n_envs);
+void        oro_destroy(oro_batch *b);
+orc_config *oro_config_ptr(oro_batch *b);
+int         oro_num_envs(const oro_batch *b);
+void        oro_set_seed(oro_batch *b, int seed);
+void        oro_reset_env(oro_batch *b, int env);
+void        oro_prune_roots(oro_batch *b, const int32_t *actions);
+void oro_search_batch(oro_batch *b, const int8_t *boards, const int32_t *turns,
+                      int8_t *out_boards, float *out_d, float *out_p1w, float *out_p2w,
+                      uint8_t *out_is_term, int32_t *out_turns, uint8_t *out_valid_mask);
+void oro_backprop_batch(oro_batch *b, const float *policy, const float *d, const float *p1w,
+                        const float *p2w, const float *moves_left, const uint8_t *is_term);
+void oro_remove_all_vl(oro_batch *b, int K);
+void oro_search_batch_vl(oro_batch *b, int K, const int8_t *boards, const int32_t *turns,
+                         int8_t *out_boards, float *out_d, float *out_p1w, float *out_p2w,
+                         uint8_t *out_is_term, int32_t *out_turns, int32_t *out_sym_ids,
+                         uint8_t *out_valid_mask);
+void oro_backprop_batch_vl(oro_batch *b, int K, const float *policy, const float *d,
+                           const float *p1w, const float *p2w, const float *moves_left,
+                           const uint8_t *is_term, const int32_t *sym_ids);
+void oro_search_rollout(oro_batch *b, const int8_t *boards, const int32_t *turns, int n_playout);
+void oro_get_all_counts(const oro_batch *b, int32_t *out /* n_envs*65 */);
+void oro_get_all_root_stats(const oro_batch *b, float *out /* n_envs*526 */);
+void oro_stats_get(const oro_batch *b, orc_stats *out);
+void oro_stats_reset(oro_batch *b);
+void oro_tree_size(const oro_batch *b, int env, int32_t *nodes, int32_t *edges);
 
 #ifdef __cplusplus
 }

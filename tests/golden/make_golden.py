@@ -256,9 +256,37 @@ def gen_g8():
     save("g8_selfplay", **out)
 
 
+# ------------------------------------------------------------------ Othello (config 4)
+def gen_othello():
+    from src.env_cpp.othello import Env as OEnv
+    for name in S.OTHELLO_SCENARIOS:
+        cfg, boards, turns, n, K, plies, seed = S.othello_scenario_inputs(name)
+        r = S.run_othello_scenario(mcts_cpp.BatchedMCTS_Othello, name, inputs=(boards, turns))
+        save(name, in_boards=boards, in_turns=turns, **r)
+    # game logic of env_cpp.othello.Env: random games with forced passes, all 8 symmetries
+    rng = np.random.default_rng(202)
+    rec = {k: [] for k in ("board", "turn", "winner", "full", "done", "mask", "state", "action", "game", "syms")}
+    for g in range(40):
+        e = OEnv()
+        while True:
+            rec["board"].append(np.asarray(e.board, np.float32).astype(np.int8))
+            rec["turn"].append(e.turn); rec["winner"].append(e.winPlayer()); rec["full"].append(e.check_full())
+            rec["done"].append(e.done()); rec["mask"].append(np.array(e.valid_mask(), np.uint8))
+            rec["state"].append(e.current_state()[0].astype(np.int8)); rec["game"].append(g)
+            rec["syms"].append(np.stack([np.asarray(e.apply_symmetry(sid).board).astype(np.int8) for sid in range(8)]))
+            if e.done():
+                rec["action"].append(-1)
+                break
+            a = int(rng.choice(e.valid_move()))
+            rec["action"].append(a)
+            e.step(a)
+    inv = np.array([[OEnv.inverse_symmetry_action(sid, a) for a in range(65)] for sid in range(8)], np.int32)
+    save("g1_othello_logic", inv_action=inv, **{k: np.array(v) for k, v in rec.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rng", "g1", "g2", "search", "g6", "rollout", "g7", "g8"]
+    which = sys.argv[1:] or ["rng", "g1", "g2", "search", "g6", "rollout", "g7", "g8", "othello"]
     fns = dict(rng=gen_rng, g1=gen_g1, g2=gen_g2, search=gen_search, g6=gen_g6,
-               rollout=gen_rollout, g7=gen_g7, g8=gen_g8)
+               rollout=gen_rollout, g7=gen_g7, g8=gen_g8, othello=gen_othello)
     for w in which:
         fns[w]()

@@ -169,11 +169,35 @@ def rel_to_abs(wdl_rel, turns):
 
 # ----------------------------------------------------------------------------- playout loop
 
-def playout(mcts, boards, turns, n_playout, K, evaluator=hash_eval, log=None):
+class C4Game:
+    """What the scenario driver needs to know about a game (Connect4 here)."""
+    A = 7
+
+    @staticmethod
+    def hash_eval(boards, turns):
+        return hash_eval(boards, turns)
+
+    @staticmethod
+    def bitboards(boards):
+        return boards_to_bitboards(boards)
+
+    @staticmethod
+    def advance(board, turn, action):
+        """Apply `action` in place if the game is still running; returns the new side to move."""
+        if not np_done(board) and 0 <= action < COLS and board[0, action] == 0:
+            np_drop(board, int(action), int(turn))
+            return -turn
+        return turn
+
+
+def playout(mcts, boards, turns, n_playout, K, evaluator=None, log=None, game=C4Game):
     """The reference wrapper's loop (MCTS_cpp.py:110-357) at the mcts_cpp level, without
     cache/time budget: K<=1 -> n_playout single sims; K>1 -> one warm-up sim then VL chunks
     of min(K, remaining)."""
     n = boards.shape[0]
+    A = game.A
+    if evaluator is None:
+        evaluator = game.hash_eval
 
     def one_plain():
         lb, td, t1, t2, it, lt, vm = mcts.search_batch(boards, turns)
@@ -219,11 +243,11 @@ def playout(mcts, boards, turns, n_playout, K, evaluator=hash_eval, log=None):
         mcts.backprop_batch_vl(k, probs, d, p1, p2, ml, it, sy)
 
 
-def counts_of(mcts, n):
+def counts_of(mcts, n, A=7):
     return np.array(mcts.get_all_counts(), np.int32).reshape(n, A)
 
 
-def play_plies(mcts, boards, turns, n_playout, K, plies, evaluator=hash_eval, record_leaves=False):
+def play_plies(mcts, boards, turns, n_playout, K, plies, evaluator=None, record_leaves=False, game=C4Game):
     """`plies` rounds of: playout -> record counts/stats -> argmax action -> prune_roots ->
     apply the move.  Finished games stay in the batch with a terminal root (reference
     behaviour in game.py:83-84 until the whole batch ends; quirk 8 of SURVEY appendix A)."""
@@ -233,8 +257,8 @@ def play_plies(mcts, boards, turns, n_playout, K, plies, evaluator=hash_eval, re
     out = dict(counts=[], stats=[], actions=[], sym=[], leaf_sig=[])
     for _ in range(plies):
         log = [] if record_leaves else None
-        playout(mcts, boards, turns, n_playout, K, evaluator, log)
-        c = counts_of(mcts, n)
+        playout(mcts, boards, turns, n_playout, K, evaluator, log, game)
+        c = counts_of(mcts, n, game.A)
         out["counts"].append(c)
         out["stats"].append(np.array(mcts.get_all_root_stats(), np.float32))
         acts = np.argmax(c, axis=1).astype(np.int32)
@@ -245,7 +269,7 @@ def play_plies(mcts, boards, turns, n_playout, K, plies, evaluator=hash_eval, re
             # order-sensitive signature of every leaf returned during this ply
             sig = np.zeros(4, np.int64)
             for e in log:
-                bb0, bb1 = boards_to_bitboards(e["boards"])
+                bb0, bb1 = game.bitboards(e["boards"])
                 h = hash64(bb0, bb1, e["turns"]).astype(np.int64)
                 w = np.arange(1, h.size + 1, dtype=np.int64)
                 with np.errstate(over="ignore"):
@@ -256,9 +280,7 @@ def play_plies(mcts, boards, turns, n_playout, K, plies, evaluator=hash_eval, re
             out["leaf_sig"].append(sig)
         mcts.prune_roots(acts)
         for i in range(n):
-            if not np_done(boards[i]) and boards[i][0, acts[i]] == 0:
-                np_drop(boards[i], int(acts[i]), int(turns[i]))
-                turns[i] = -turns[i]
+            turns[i] = game.advance(boards[i], int(turns[i]), int(acts[i]))
     res = dict(counts=np.stack(out["counts"]), stats=np.stack(out["stats"]),
                actions=np.stack(out["actions"]), final_boards=boards, final_turns=turns)
     if record_leaves:
@@ -328,3 +350,176 @@ def run_search_scenario(make_mcts, name):
     if seed is not None:
         m.set_seed(seed)
     return play_plies(m, boards, turns, n, K, plies, record_leaves=True)
+
+
+# ============================================================================= Othello
+
+OT_A = 65
+OT_PASS = 64
+_DIRS = [(-1, 0), (-1, 1), (0, 1), (1, 1), (1, 0), (1, -1), (0, -1), (-1, -1)]
+
+
+def ot_start():
+    b = np.zeros((8, 8), np.int8)
+    b[3, 3] = -1; b[3, 4] = 1; b[4, 3] = 1; b[4, 4] = -1     # Othello.h:63-78
+    return b
+
+
+def ot_flips(board, turn, r, c):
+    out = []
+    for dr, dc in _DIRS:
+        line = []
+        rr, cc = r + dr, c + dc
+        while 0 <= rr < 8 and 0 <= cc < 8 and board[rr, cc] == -turn:
+            line.append((rr, cc)); rr += dr; cc += dc
+        if line and 0 <= rr < 8 and 0 <= cc < 8 and board[rr, cc] == turn:
+            out += line
+    return out
+
+
+def ot_moves(board, turn):
+    return [r * 8 + c for r in range(8) for c in range(8)
+            if board[r, c] == 0 and ot_flips(board, turn, r, c)]
+
+
+def ot_over(board):
+    return not (board == 0).any() or (not ot_moves(board, 1) and not ot_moves(board, -1))
+
+
+def ot_play(board, turn, action):
+    r, c = divmod(int(action), 8)
+    for rr, cc in ot_flips(board, turn, r, c):
+        board[rr, cc] = turn
+    board[r, c] = turn
+
+
+def ot_openings(rng, n, max_plies, want_pass=0):
+    """n legal, unfinished Othello positions after 0..max_plies random plies (passes when
+    forced).  The first `want_pass` of them are positions where the side to move must pass."""
+    boards = np.zeros((n, 8, 8), np.int8)
+    turns = np.zeros(n, np.int32)
+    i = 0
+    while i < n:
+        b = ot_start(); t = 1
+        for _ in range(int(rng.integers(0, max_plies + 1))):
+            mv = ot_moves(b, t)
+            if mv:
+                ot_play(b, t, int(rng.choice(mv)))
+            t = -t
+            if ot_over(b):
+                break
+        if ot_over(b):
+            continue
+        must_pass = not ot_moves(b, t)
+        if i < want_pass and not must_pass:
+            continue
+        boards[i] = b; turns[i] = t
+        i += 1
+    return boards, turns
+
+
+def ot_bitboards(boards):
+    """(n,8,8) int8 -> (black, white) uint64, bit = row*8 + col (Othello.h:18-23)."""
+    flat = np.asarray(boards).reshape(len(boards), 64)
+    w = (np.uint64(1) << np.arange(64, dtype=np.uint64))
+    bb0 = ((flat == 1).astype(np.uint64) * w).sum(1, dtype=np.uint64)
+    bb1 = ((flat == -1).astype(np.uint64) * w).sum(1, dtype=np.uint64)
+    return bb0, bb1
+
+
+def ot_hash_eval(boards, turns):
+    """HashEval for Othello: 65 policy values from five re-mixed words (4 bits each), WDL from
+    three 5-bit weights, auxiliary utility = 6 bits / 32 - 1 in [-1, 1); all exact in fp32."""
+    bb0, bb1 = ot_bitboards(boards)
+    h = hash64(bb0, bb1, np.asarray(turns))
+    n = h.shape[0]
+    probs = np.empty((n, OT_A), np.float32)
+    with np.errstate(over="ignore"):
+        for k in range(5):
+            hk = h + np.uint64(0x9E3779B97F4A7C15) * np.uint64(k + 1)
+            hk ^= hk >> np.uint64(29); hk *= np.uint64(0xBF58476D1CE4E5B9); hk ^= hk >> np.uint64(32)
+            for j in range(16):
+                a = k * 16 + j
+                if a < OT_A:
+                    probs[:, a] = (1 + ((hk >> np.uint64(4 * j)) & np.uint64(15))).astype(np.float32) / np.float32(16)
+    w = np.stack([1 + ((h >> np.uint64(s)) & np.uint64(31)) for s in (28, 33, 38)], axis=1)
+    wdl = w.astype(np.float32) / w.sum(axis=1, keepdims=True).astype(np.float32)
+    aux = ((h >> np.uint64(43)) & np.uint64(63)).astype(np.float32) / np.float32(32) - np.float32(1)
+    return probs, wdl.astype(np.float32), aux
+
+
+class OthelloGame:
+    A = OT_A
+
+    @staticmethod
+    def hash_eval(boards, turns):
+        return ot_hash_eval(boards, turns)
+
+    @staticmethod
+    def bitboards(boards):
+        return ot_bitboards(boards)
+
+    @staticmethod
+    def advance(board, turn, action):
+        if ot_over(board):
+            return turn
+        if action == OT_PASS:
+            return -turn if not ot_moves(board, turn) else turn
+        r, c = divmod(int(action), 8)
+        if board[r, c] == 0 and ot_flips(board, turn, r, c):
+            ot_play(board, turn, action)
+            return -turn
+        return turn
+
+
+# server defaults for Othello (server.py:44-72; SURVEY 8d C3): score utility on, MLH ignored
+OT_ACTOR_CFG = dict(c_init=1.4, c_base=2000.0, dirichlet_alpha=0.3, noise_epsilon=0.25, fpu_reduction=0.2,
+                    mlh_slope=0.1, mlh_cap=0.2, score_utility_factor=0.15, score_scale=8.0,
+                    value_decay=1.0, use_symmetry=True, vl_count=1)
+OT_DET_CFG = dict(OT_ACTOR_CFG, dirichlet_alpha=0.0, noise_epsilon=0.0, use_symmetry=False)
+
+
+_OT_SCEN = {
+    # name: (cfg, (n_positions, max_plies, want_pass), n_playout, K, plies, seed)
+    "ot_det_n60_k4": (dict(OT_DET_CFG, c_base=300.0), (32, 20, 0), 60, 4, 6, None),
+    "ot_det_n100_k1": (dict(OT_DET_CFG, c_base=500.0), (16, 30, 0), 100, 1, 4, None),
+    "ot_seeded_actor": (dict(OT_ACTOR_CFG, c_base=250.0), (24, 16, 0), 50, 4, 5, 4321),
+    # late positions: forced passes, double-pass terminals, full boards
+    "ot_endgames_passes": (dict(OT_DET_CFG, c_base=240.0), (40, 58, 6), 48, 4, 8, None),
+    "ot_no_score_utility_decay": (dict(OT_DET_CFG, score_utility_factor=0.0, value_decay=0.96, vl_count=2,
+                                       c_base=320.0), (16, 24, 0), 64, 4, 4, None),
+}
+
+
+def _othello_scenario_params(name):
+    cfg, _, n, K, plies, seed = _OT_SCEN[name]
+    return cfg, None, None, n, K, plies, seed
+
+
+def othello_scenario_inputs(name):
+    cfg, (npos, max_plies, want_pass), n, K, plies, seed = _OT_SCEN[name]
+    rng = np.random.default_rng(int.from_bytes(name.encode(), "little") % (2 ** 31))
+    b, t = ot_openings(rng, npos, max_plies, want_pass)
+    return cfg, b, t, n, K, plies, seed
+
+
+othello_scenario_inputs.__wrapped__ = _othello_scenario_params
+
+
+OTHELLO_SCENARIOS = ["ot_det_n60_k4", "ot_det_n100_k1", "ot_seeded_actor", "ot_endgames_passes",
+                     "ot_no_score_utility_decay"]
+
+
+def run_othello_scenario(make_mcts, name, inputs=None):
+    """inputs = (boards, turns) replays stored start positions (the fixtures keep them: finding
+    forced-pass positions by random play in Python is slow)."""
+    if inputs is None:
+        cfg, boards, turns, n, K, plies, seed = othello_scenario_inputs(name)
+    else:
+        cfg, _, _, n, K, plies, seed = othello_scenario_inputs.__wrapped__(name)
+        boards, turns = inputs
+    m = make_mcts(boards.shape[0])
+    apply_cfg(m, cfg)
+    if seed is not None:
+        m.set_seed(seed)
+    return play_plies(m, boards, turns, n, K, plies, record_leaves=True, game=OthelloGame)

@@ -176,3 +176,42 @@ def test_g9_rollout_search():
     m.search_rollout(g["boards"], g["turns"], 120)
     assert np.array_equal(S.counts_of(m, 12), g["counts"])
     assert np.array_equal(bits(m.get_all_root_stats()), bits(g["stats"]))
+
+
+# ------------------------------------------------------------------ Othello (a32, config 4)
+def check_othello(name, make):
+    g = load(name)
+    got = S.run_othello_scenario(make, name, inputs=(g["in_boards"], g["in_turns"]))
+    assert np.array_equal(got["counts"], g["counts"]), "visit counts"
+    assert np.array_equal(got["actions"], g["actions"])
+    assert np.array_equal(bits(got["stats"]), bits(g["stats"])), "root stats"
+    assert np.array_equal(got["sym"], g["sym"]), "symmetry ids"
+    assert np.array_equal(got["leaf_sig"], g["leaf_sig"]), "leaf outputs"
+    assert np.array_equal(got["final_boards"], g["final_boards"])
+
+
+@pytest.mark.parametrize("name", S.OTHELLO_SCENARIOS)
+def test_othello_search_scenarios(name):
+    check_othello(name, O.BatchedMCTS_Othello)
+
+
+def replay_othello_env(make_env):
+    g = load("g1_othello_logic")
+    e = None
+    for i in range(len(g["game"])):
+        if i == 0 or g["game"][i] != g["game"][i - 1]:
+            e = make_env()
+        assert np.array_equal(np.asarray(e.board).astype(np.int8), g["board"][i])
+        assert e.turn == g["turn"][i] and e.winPlayer() == g["winner"][i]
+        assert e.check_full() == bool(g["full"][i]) and e.done() == bool(g["done"][i])
+        assert np.array_equal(np.array(e.valid_mask(), np.uint8), g["mask"][i])
+        assert np.array_equal(e.current_state()[0].astype(np.int8), g["state"][i])
+        for sid in range(8):
+            assert np.array_equal(np.asarray(e.apply_symmetry(sid).board).astype(np.int8), g["syms"][i][sid])
+        if g["action"][i] >= 0:
+            e.step(int(g["action"][i]))
+    return g
+
+
+def test_othello_game_logic():
+    replay_othello_env(O.OthelloEnv)
