@@ -55,25 +55,26 @@ struct DevBuf {
 };
 
 struct LeafStore {
-    DevBuf<int32_t> slot, turn, path_len, path, sym;
+    DevBuf<int32_t> slot, turn, aux, path_len, path, sym;
     DevBuf<uint64_t> bb0, bb1;
-    DevBuf<uint8_t> flags;
+    DevBuf<uint8_t> flags, nvalid;
+    int max_path = az::C4_MAX_PATH;
     void ensure(size_t leaves)
     {
         const bool grow = leaves > slot.n;
-        slot.ensure(leaves); turn.ensure(leaves); bb0.ensure(leaves); bb1.ensure(leaves);
-        sym.ensure(leaves, true);
+        slot.ensure(leaves); turn.ensure(leaves); aux.ensure(leaves, true); bb0.ensure(leaves); bb1.ensure(leaves);
+        sym.ensure(leaves, true); nvalid.ensure(leaves, true);
         if (grow) {
             flags.ensure(leaves, true);
             path_len.ensure(leaves, true);   // 0 == "no descent recorded" (current_leaf_idx == -1)
-            path.ensure(leaves * az::C4_MAX_PATH);
+            path.ensure(leaves * max_path);
         }
     }
     az::LeafBuf view()
     {
         az::LeafBuf v;
-        v.slot = slot.p; v.bb0 = bb0.p; v.bb1 = bb1.p; v.turn = turn.p; v.flags = flags.p;
-        v.path_len = path_len.p; v.path = path.p; v.sym = sym.p;
+        v.slot = slot.p; v.bb0 = bb0.p; v.bb1 = bb1.p; v.turn = turn.p; v.aux = aux.p; v.nvalid = nvalid.p;
+        v.flags = flags.p; v.path_len = path_len.p; v.path = path.p; v.sym = sym.p;
         return v;
     }
 };
@@ -115,9 +116,18 @@ struct EventRing {
     }
 };
 
-constexpr int A = az::C4_ACTIONS;
-constexpr int CELLS = az::C4_CELLS;
-constexpr int STATS = az::C4_STATS;
+// static geometry of a game as the host needs it
+struct Geo {
+    int actions, cells, rows, cols, stats, max_path, sym_choices;
+};
+
+Geo geo_of(int game)
+{
+    if (game == AZ_GAME_OTHELLO)
+        return Geo{az::OT_ACTIONS, az::OT_CELLS, 8, 8, az::OT_STATS, az::OT_MAX_PATH, 4};
+    return Geo{az::C4_ACTIONS, az::C4_CELLS, az::C4_ROWS, az::C4_COLS, az::C4_STATS, az::C4_MAX_PATH, 2};
+}
+
 constexpr int64_t kInitialSlots = 4096;
 constexpr int kCpuctTab = 1 << 16;
 
@@ -125,6 +135,7 @@ constexpr int kCpuctTab = 1 << 16;
 
 struct az_mcts {
     int game = AZ_GAME_CONNECT4;
+    Geo geo = geo_of(AZ_GAME_CONNECT4);
     int B = 0;
     int device = 0;
     az_search_config cfg;
@@ -148,6 +159,8 @@ struct az_mcts {
     // c_puct table
     DevBuf<float> tab;
     float tab_c_init = NAN, tab_c_base = NAN;
+    DevBuf<float> term_tab;   // Othello terminal_aux by diff*turn + 64
+    float term_tab_scale = NAN;
 
     DevBuf<unsigned long long> counters;
     DevBuf<int> err;
@@ -179,12 +192,24 @@ struct az_mcts {
     az::RootState roots()
     {
         az::RootState r;
-        r.bb0 = r_bb0.p; r.bb1 = r_bb1.p; r.turn = r_turn.p; r.last = r_last.p;
+        r.bb0 = r_bb0.p; r.bb1 = r_bb1.p; r.turn = r_turn.p; r.aux = r_last.p;
         return r;
     }
 
     void ensure_table()
     {
+        // Othello.h:260-266 with the host libm: atanf(raw / scale) * (2.0f / 3.14159265f)
+        if (!term_tab.p || cfg.score_scale != term_tab_scale) {
+            std::vector<float> h(129);
+            for (int i = 0; i < 129; ++i) {
+                const float raw = static_cast<float>(i - 64);
+                h[i] = std::atan(raw / cfg.score_scale) * (2.0f / 3.14159265f);
+            }
+            if (!term_tab.p) ++epoch;
+            term_tab.ensure(129);
+            HIP_OK(hipMemcpy(term_tab.p, h.data(), sizeof(float) * 129, hipMemcpyHostToDevice));
+            term_tab_scale = cfg.score_scale;
+        }
         // logf through the host libm, float arithmetic in the reference's order (MCTS.h:213-214)
         if (tab.p && cfg.c_init == tab_c_init && cfg.c_base == tab_c_base) return;
         std::vector<float> h(kCpuctTab);
@@ -206,6 +231,7 @@ struct az_mcts {
         p.c_init = cfg.c_init; p.c_base = cfg.c_base; p.noise_eps = cfg.noise_epsilon;
         p.fpu_reduction = cfg.fpu_reduction; p.mlh_slope = cfg.mlh_slope; p.mlh_cap = cfg.mlh_cap;
         p.value_decay = cfg.value_decay; p.alpha = cfg.dirichlet_alpha;
+        p.score_utility_factor = cfg.score_utility_factor; p.term_aux_tab = term_tab.p;
         p.vl_count = cfg.vl_count; p.use_symmetry = cfg.use_symmetry ? 1 : 0;
         p.cpuct_tab = tab.p; p.tab_n = kCpuctTab;
         p.seed = dev_seed; p.call_ptr = call_ctr.p;
@@ -272,7 +298,7 @@ namespace {
 
 az_mcts *create_engine(int game, int n_envs, int device)
 {
-    if (game != AZ_GAME_CONNECT4) throw AzError(AZ_ERR_ARG, "unknown game id");
+    if (game != AZ_GAME_CONNECT4 && game != AZ_GAME_OTHELLO) throw AzError(AZ_ERR_ARG, "unknown game id");
     if (n_envs <= 0) throw AzError(AZ_ERR_ARG, "n_envs must be positive");
     int count = 0;
     const hipError_t dev_err = hipGetDeviceCount(&count);
@@ -283,6 +309,9 @@ az_mcts *create_engine(int game, int n_envs, int device)
     auto *m = new az_mcts();
     try {
         HIP_OK(hipGetDevice(&m->device));
+        m->game = game;
+        m->geo = geo_of(game);
+        m->vl_leaf.max_path = m->plain_leaf.max_path = m->geo.max_path;
         m->B = n_envs;
         m->cfg.c_init = 1.25f; m->cfg.c_base = 19652.0f; m->cfg.dirichlet_alpha = 0.3f;
         m->cfg.noise_epsilon = 0.25f; m->cfg.fpu_reduction = 0.4f; m->cfg.mlh_slope = 0.0f;
@@ -340,22 +369,24 @@ void host_search(az_mcts *m, int K, bool vl, const int8_t *boards, const int32_t
     hipStream_t s = nullptr;
     m->flush_resets(s);
 
+    const int A = m->geo.actions, CELLS = m->geo.cells;
     m->io_boards_in.ensure(static_cast<size_t>(B) * CELLS);
     m->io_turns_in.ensure(B);
     HIP_OK(hipMemcpy(m->io_boards_in.p, boards, static_cast<size_t>(B) * CELLS, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(m->io_turns_in.p, turns, sizeof(int32_t) * B, hipMemcpyHostToDevice));
-    az::launch_import(m->io_boards_in.p, m->io_turns_in.p, m->roots(), B, s);
+    az::launch_import(m->game, m->io_boards_in.p, m->io_turns_in.p, m->roots(), B, s);
 
     LeafStore &ls = vl ? m->vl_leaf : m->plain_leaf;
     ls.ensure(total);
     if (vl) m->vl_stride = K;
     m->last_select_vl = vl;
     const az::SearchParams p = m->params();
-    az::launch_select(m->arena(), m->roots(), ls.view(), p, K, vl, m->counters.p, s);
+    az::launch_select(m->game, m->arena(), m->roots(), ls.view(), p, K, vl, m->counters.p, s);
     ++m->select_launches;
 
-    std::vector<uint8_t> flags(total);
+    std::vector<uint8_t> flags(total), nvalid(total);
     HIP_OK(hipMemcpy(flags.data(), ls.flags.p, total, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(nvalid.data(), ls.nvalid.p, total, hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(out_turns, ls.turn.p, sizeof(int32_t) * total, hipMemcpyDeviceToHost));
 
     // symmetry ids in env order, one draw per NON-terminal leaf (BatchedMCTS.h:148-158,261-271)
@@ -368,25 +399,30 @@ void host_search(az_mcts *m, int K, bool vl, const int8_t *boards, const int32_t
         out_d[f] = (term && code == 0) ? 1.0f : 0.0f;
         out_p1w[f] = (term && code == 1) ? 1.0f : 0.0f;
         out_p2w[f] = (term && code == 2) ? 1.0f : 0.0f;
-        if (!term && use_sym) sym[f] = m->rng.uniform_int(1);
+        if (!term && use_sym) {               // Connect4: id in {0,1}; Othello: {0,2,6,7}[index] (Othello.h:363-367)
+            const int choice = m->rng.uniform_int(m->geo.sym_choices - 1);
+            static const int ot_ids[4] = {0, 2, 6, 7};
+            sym[f] = m->game == AZ_GAME_OTHELLO ? ot_ids[choice] : choice;
+        }
     }
     if (out_sym) std::memcpy(out_sym, sym.data(), sizeof(int32_t) * total);
     HIP_OK(hipMemcpy(ls.sym.p, sym.data(), sizeof(int32_t) * total, hipMemcpyHostToDevice));
 
     m->io_boards_out.ensure(total * CELLS);
     m->io_mask_out.ensure(total * A);
-    az::launch_export(ls.view(), p, static_cast<int>(total), false, m->io_boards_out.p,
+    az::launch_export(m->game, ls.view(), p, static_cast<int>(total), false, m->io_boards_out.p,
                       m->io_mask_out.p, nullptr, s);
     HIP_OK(hipMemcpy(out_boards, m->io_boards_out.p, total * CELLS, hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(out_mask, m->io_mask_out.p, total * A, hipMemcpyDeviceToHost));
 
-    // what the host generator needs at expansion time
+    // what the host generator needs at expansion time: which leaves are unexpanded roots and how
+    // many legal moves (= noise draws) such a root has
+    for (int i = 0; i < B; ++i)
+        for (int k = 0; k < K; ++k) {
+            const size_t f = static_cast<size_t>(i) * K + k;
+            if (flags[f] & az::LEAF_ROOT_UNEXPANDED) { m->stash_root_nv[i] = nvalid[f]; break; }
+        }
     (vl ? m->stash_flags_vl : m->stash_flags_plain) = std::move(flags);
-    for (int i = 0; i < B; ++i) {
-        int nv = 0;
-        for (int c = 0; c < az::C4_COLS; ++c) nv += boards[static_cast<size_t>(i) * CELLS + c] == 0;
-        m->stash_root_nv[i] = static_cast<uint8_t>(nv);
-    }
 }
 
 // Shared body of backprop_batch / backprop_batch_vl (BatchedMCTS.h:176-199, 296-332)
@@ -395,6 +431,7 @@ void host_backprop(az_mcts *m, int K, bool vl, const float *policy, const float 
 {
     HIP_OK(hipSetDevice(m->device));
     const int B = m->B;
+    const int A = m->geo.actions;
     hipStream_t s = nullptr;
     m->flush_resets(s);
     LeafStore &ls = vl ? m->vl_leaf : m->plain_leaf;
@@ -442,7 +479,7 @@ void host_backprop(az_mcts *m, int K, bool vl, const float *policy, const float 
         HIP_OK(hipMemcpy(m->io_sym_in.p, sym_ids, sizeof(int32_t) * total, hipMemcpyHostToDevice));
         in.sym = m->io_sym_in.p;
     }
-    az::launch_backprop(m->arena(), ls.view(), m->params(), K, vl, false, in, m->counters.p, m->err.p, s);
+    az::launch_backprop(m->game, m->arena(), ls.view(), m->params(), K, vl, false, in, m->counters.p, m->err.p, s);
     ++m->backprop_launches;
     HIP_OK(hipStreamSynchronize(s));
     m->check_device_error();
@@ -456,10 +493,11 @@ extern "C" {
 
 const char *az_last_error(void) { return g_last_error.c_str(); }
 
-int az_game_action_size(int game) { return game == AZ_GAME_CONNECT4 ? az::C4_ACTIONS : -1; }
-int az_game_board_size(int game) { return game == AZ_GAME_CONNECT4 ? az::C4_CELLS : -1; }
-int az_game_board_rows(int game) { return game == AZ_GAME_CONNECT4 ? az::C4_ROWS : -1; }
-int az_game_board_cols(int game) { return game == AZ_GAME_CONNECT4 ? az::C4_COLS : -1; }
+static bool known_game(int game) { return game == AZ_GAME_CONNECT4 || game == AZ_GAME_OTHELLO; }
+int az_game_action_size(int game) { return known_game(game) ? geo_of(game).actions : -1; }
+int az_game_board_size(int game) { return known_game(game) ? geo_of(game).cells : -1; }
+int az_game_board_rows(int game) { return known_game(game) ? geo_of(game).rows : -1; }
+int az_game_board_cols(int game) { return known_game(game) ? geo_of(game).cols : -1; }
 
 int az_mcts_create(int game, int n_envs, int device, az_mcts **out)
 {
@@ -513,10 +551,11 @@ int az_mcts_prune_roots(az_mcts *m, const int32_t *actions, int64_t n)
         hipStream_t s = nullptr;
         m->flush_resets(s);
         const int B = m->B;
+        const int A = m->geo.actions;
         m->io_actions.ensure(B); m->io_noise_req.ensure(B, true);
         HIP_OK(hipMemcpy(m->io_actions.p, actions, sizeof(int32_t) * B, hipMemcpyHostToDevice));
         const az::SearchParams p = m->params();
-        az::launch_prune(m->arena(), p, m->io_actions.p, m->io_noise_req.p, false, s);
+        az::launch_prune(m->game, m->arena(), p, m->io_actions.p, m->io_noise_req.p, false, s);
         if (m->cfg.dirichlet_alpha > 0.0f) {  // apply_root_noise, env order (MCTS.h:113-132)
             std::vector<int32_t> req(B);
             HIP_OK(hipMemcpy(req.data(), m->io_noise_req.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
@@ -530,7 +569,7 @@ int az_mcts_prune_roots(az_mcts *m, const int32_t *actions, int64_t n)
             if (any) {
                 m->io_noise.ensure(static_cast<size_t>(B) * A);
                 HIP_OK(hipMemcpy(m->io_noise.p, noise.data(), sizeof(float) * noise.size(), hipMemcpyHostToDevice));
-                az::launch_apply_noise(m->arena(), m->io_noise_req.p, m->io_noise.p, s);
+                az::launch_apply_noise(m->game, m->arena(), m->io_noise_req.p, m->io_noise.p, s);
             }
         }
         HIP_OK(hipStreamSynchronize(s));
@@ -567,7 +606,7 @@ int az_mcts_remove_all_vl(az_mcts *m, int K)
         HIP_OK(hipSetDevice(m->device));
         if (m->vl_stride <= 0 || K <= 0) return;
         const int kk = std::min(K, m->vl_stride);          // safe_K, MCTS.h:563
-        az::launch_remove_vl(m->arena(), m->vl_leaf.view(), m->params(), kk, m->vl_stride, nullptr);
+        az::launch_remove_vl(m->game, m->arena(), m->vl_leaf.view(), m->params(), kk, m->vl_stride, nullptr);
         HIP_OK(hipStreamSynchronize(nullptr));
     });
 }
@@ -612,13 +651,14 @@ int az_mcts_search_rollout(az_mcts *m, const int8_t *boards, const int32_t *turn
         require(n_playout >= 0, "search: n_playout must be >= 0");
         HIP_OK(hipSetDevice(m->device));
         const int B = m->B;
+        const int A = m->geo.actions, CELLS = m->geo.cells;
         hipStream_t s = nullptr;
         m->flush_resets(s);
         m->io_boards_in.ensure(static_cast<size_t>(B) * CELLS);
         m->io_turns_in.ensure(B);
         HIP_OK(hipMemcpy(m->io_boards_in.p, boards, static_cast<size_t>(B) * CELLS, hipMemcpyHostToDevice));
         HIP_OK(hipMemcpy(m->io_turns_in.p, turns, sizeof(int32_t) * B, hipMemcpyHostToDevice));
-        az::launch_import(m->io_boards_in.p, m->io_turns_in.p, m->roots(), B, s);
+        az::launch_import(m->game, m->io_boards_in.p, m->io_turns_in.p, m->roots(), B, s);
         m->plain_leaf.ensure(B);
         HIP_OK(hipMemset(m->plain_leaf.sym.p, 0, sizeof(int32_t) * B));
         m->io_policy.ensure(static_cast<size_t>(B) * A); m->io_d.ensure(B); m->io_p1.ensure(B);
@@ -630,10 +670,10 @@ int az_mcts_search_rollout(az_mcts *m, const int8_t *boards, const int32_t *turn
         in.is_term = m->io_is_term.p; in.moves_left = m->io_ml.p; in.sym = nullptr; in.root_noise = nullptr;
         m->last_select_vl = false;
         for (int it = 0; it < n_playout; ++it) {
-            az::launch_select(m->arena(), m->roots(), m->plain_leaf.view(), p, 1, false, m->counters.p, s);
-            az::launch_rollout(m->plain_leaf.view(), p, B, m->io_policy.p, m->io_d.p, m->io_p1.p, m->io_p2.p,
+            az::launch_select(m->game, m->arena(), m->roots(), m->plain_leaf.view(), p, 1, false, m->counters.p, s);
+            az::launch_rollout(m->game, m->plain_leaf.view(), p, B, m->io_policy.p, m->io_d.p, m->io_p1.p, m->io_p2.p,
                                m->io_ml.p, m->io_is_term.p, s);
-            az::launch_backprop(m->arena(), m->plain_leaf.view(), p, 1, false, false, in, m->counters.p, m->err.p, s);
+            az::launch_backprop(m->game, m->arena(), m->plain_leaf.view(), p, 1, false, false, in, m->counters.p, m->err.p, s);
             az::launch_bump_call(m->call_ctr.p, s);
         }
         m->select_launches += n_playout;
@@ -648,8 +688,9 @@ int az_mcts_get_all_counts(az_mcts *m, int32_t *out)
     return guarded([&] {
         HIP_OK(hipSetDevice(m->device));
         m->flush_resets(nullptr);
+        const int A = m->geo.actions;
         m->io_counts.ensure(static_cast<size_t>(m->B) * A);
-        az::launch_counts(m->arena(), m->io_counts.p, nullptr);
+        az::launch_counts(m->game, m->arena(), m->io_counts.p, nullptr);
         HIP_OK(hipMemcpy(out, m->io_counts.p, sizeof(int32_t) * m->B * A, hipMemcpyDeviceToHost));
     });
 }
@@ -659,8 +700,9 @@ int az_mcts_get_all_root_stats(az_mcts *m, float *out)
     return guarded([&] {
         HIP_OK(hipSetDevice(m->device));
         m->flush_resets(nullptr);
+        const int STATS = m->geo.stats;
         m->io_stats.ensure(static_cast<size_t>(m->B) * STATS);
-        az::launch_root_stats(m->arena(), m->io_stats.p, nullptr);
+        az::launch_root_stats(m->game, m->arena(), m->io_stats.p, nullptr);
         HIP_OK(hipMemcpy(out, m->io_stats.p, sizeof(float) * m->B * STATS, hipMemcpyDeviceToHost));
     });
 }
@@ -677,7 +719,7 @@ int az_mcts_dev_prepare(az_mcts *m, int K, int64_t sims_per_tree)
         m->vl_leaf.ensure(static_cast<size_t>(m->B) * K);
         m->plain_leaf.ensure(m->B);
         m->ensure_table();
-        m->ensure_room(sims_per_tree * A);
+        m->ensure_room(sims_per_tree * m->geo.actions);
     });
 }
 
@@ -685,14 +727,14 @@ int az_mcts_dev_set_roots(az_mcts *m, const uint64_t *bb_p1, const uint64_t *bb_
                           const int32_t *turns, void *stream)
 {
     return guarded([&] {
-        az::launch_set_roots(bb_p1, bb_p2, turns, m->roots(), m->B, static_cast<hipStream_t>(stream));
+        az::launch_set_roots(m->game, bb_p1, bb_p2, turns, m->roots(), m->B, static_cast<hipStream_t>(stream));
     });
 }
 
 int az_mcts_dev_import_roots(az_mcts *m, const int8_t *boards, const int32_t *turns, void *stream)
 {
     return guarded([&] {
-        az::launch_import(boards, turns, m->roots(), m->B, static_cast<hipStream_t>(stream));
+        az::launch_import(m->game, boards, turns, m->roots(), m->B, static_cast<hipStream_t>(stream));
     });
 }
 
@@ -708,9 +750,9 @@ int az_mcts_dev_select(az_mcts *m, int K, int vl, float *features, uint8_t *vali
         m->last_select_vl = vl != 0;
         const az::SearchParams p = m->params();
         const bool timed = m->profiling && m->ev_select.begin(s);
-        az::launch_select(m->arena(), m->roots(), ls.view(), p, K, vl != 0, m->counters.p, s);
+        az::launch_select(m->game, m->arena(), m->roots(), ls.view(), p, K, vl != 0, m->counters.p, s);
         if (timed) m->ev_select.end(s);
-        az::launch_export(ls.view(), p, static_cast<int>(total), true, nullptr, valid_mask, features, s);
+        az::launch_export(m->game, ls.view(), p, static_cast<int>(total), true, nullptr, valid_mask, features, s);
         az::launch_bump_call(m->call_ctr.p, s);
         ++m->select_launches;
     });
@@ -728,7 +770,7 @@ int az_mcts_dev_backprop(az_mcts *m, int K, int vl, const float *probs, const fl
         in.root_noise = nullptr; in.sym = nullptr;
         hipStream_t s = static_cast<hipStream_t>(stream);
         const bool timed = m->profiling && m->ev_backprop.begin(s);
-        az::launch_backprop(m->arena(), ls.view(), m->params(), K, vl != 0, true, in, m->counters.p,
+        az::launch_backprop(m->game, m->arena(), ls.view(), m->params(), K, vl != 0, true, in, m->counters.p,
                             m->err.p, s);
         if (timed) m->ev_backprop.end(s);
         az::launch_bump_call(m->call_ctr.p, s);
@@ -753,19 +795,19 @@ int az_mcts_dev_leaves(az_mcts *m, int K, uint64_t *bb_p1, uint64_t *bb_p2, int3
 
 int az_mcts_dev_counts(az_mcts *m, int32_t *counts, void *stream)
 {
-    return guarded([&] { az::launch_counts(m->arena(), counts, static_cast<hipStream_t>(stream)); });
+    return guarded([&] { az::launch_counts(m->game, m->arena(), counts, static_cast<hipStream_t>(stream)); });
 }
 
 int az_mcts_dev_root_stats(az_mcts *m, float *stats, void *stream)
 {
-    return guarded([&] { az::launch_root_stats(m->arena(), stats, static_cast<hipStream_t>(stream)); });
+    return guarded([&] { az::launch_root_stats(m->game, m->arena(), stats, static_cast<hipStream_t>(stream)); });
 }
 
 int az_mcts_dev_prune_roots(az_mcts *m, const int32_t *actions, void *stream)
 {
     return guarded([&] {
         hipStream_t s = static_cast<hipStream_t>(stream);
-        az::launch_prune(m->arena(), m->params(), actions, nullptr, true, s);
+        az::launch_prune(m->game, m->arena(), m->params(), actions, nullptr, true, s);
         az::launch_bump_call(m->call_ctr.p, s);
     });
 }
@@ -794,8 +836,8 @@ int az_c4_dev_step(uint64_t *bb_p1, uint64_t *bb_p2, int32_t *turns, const int32
     return guarded([&] {
         require(n >= 0, "az_c4_dev_step: negative size");
         if (n == 0) return;
-        az::launch_c4_step(bb_p1, bb_p2, turns, actions, done, winner, n, reset_finished != 0,
-                           static_cast<hipStream_t>(stream));
+        az::launch_game_step(AZ_GAME_CONNECT4, bb_p1, bb_p2, turns, actions, done, winner, n, reset_finished != 0,
+                             static_cast<hipStream_t>(stream));
     });
 }
 

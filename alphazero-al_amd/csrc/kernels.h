@@ -14,6 +14,7 @@ namespace az {
 // (MCTSNode.h:47-61) plus what the device needs besides.
 struct SearchParams {
     float c_init, c_base, noise_eps, fpu_reduction, mlh_slope, mlh_cap, value_decay, alpha;
+    float score_utility_factor;
     int   vl_count;
     int   use_symmetry;
     // c_puct(parent_n) = c_init + logf((parent_n + c_base + 1)/c_base) for parent_n < tab_n,
@@ -21,6 +22,9 @@ struct SearchParams {
     // logf takes (MCTS.h:213-214).
     const float *cpuct_tab;
     int   tab_n;
+    // Othello terminal_aux = atanf(diff*turn / score_scale) * (2/pi) (Othello.h:260-266) for
+    // diff*turn in [-64, 64], tabulated by the host libm for the same reason
+    const float *term_aux_tab;
     // device generator key (used by the dev_* entry points only).  `call_ptr` points at a
     // counter in HBM that a one-thread kernel bumps after every use, so that a captured
     // hipGraph draws fresh numbers on every replay.
@@ -37,11 +41,13 @@ struct TreeArena {
     int      B;      // trees
 };
 
-// Root positions of the current call (Connect4: two bitboards + side to move + last mover)
+// Root positions of the current call: two bitboards + side to move + the game's small integer
+// (Connect4: index of the last mover, -1 on an empty board, Connect4.h:124-128; Othello:
+// consecutive passes, 0 after an import, Othello.h:108-110)
 struct RootState {
     uint64_t *bb0, *bb1;
     int32_t  *turn;
-    int32_t  *last;  // index of the last mover (0/1), -1 when the board is empty (Connect4.h:124-128)
+    int32_t  *aux;
 };
 
 // What a descent leaves behind for expansion/backup; flat index = tree*K + k
@@ -49,9 +55,11 @@ struct LeafBuf {
     int32_t  *slot;      // leaf node
     uint64_t *bb0, *bb1; // leaf position (unsymmetrised)
     int32_t  *turn;      // side to move at the leaf
+    int32_t  *aux;       // the game's small integer at the leaf (see RootState)
+    uint8_t  *nvalid;    // legal moves at the leaf (what an expansion will append)
     uint8_t  *flags;     // LEAF_*
     int32_t  *path_len;  // nodes on the path, root first (0 = no descent recorded)
-    int32_t  *path;      // [flat*C4_MAX_PATH + depth]
+    int32_t  *path;      // [flat*MAX_PATH + depth]
     int32_t  *sym;       // symmetry id shown to the evaluator
 };
 
@@ -73,29 +81,30 @@ struct EvalIn {
 enum : int { CNT_SIMS = 0, CNT_LEVELS, CNT_EXPANSIONS, CNT_TERMINAL, CNT_DUP, CNT_BACKUP,
              CNT_SELECT_LAUNCHES, CNT_BACKPROP_LAUNCHES, CNT_N };
 
-void launch_import(const int8_t *boards, const int32_t *turns, RootState rs, int B, hipStream_t s);
-void launch_set_roots(const uint64_t *bb0, const uint64_t *bb1, const int32_t *turns, RootState rs,
+// Every launcher takes the game id (AZ_GAME_*) and dispatches to the kernel instantiation.
+void launch_import(int game, const int8_t *boards, const int32_t *turns, RootState rs, int B, hipStream_t s);
+void launch_set_roots(int game, const uint64_t *bb0, const uint64_t *bb1, const int32_t *turns, RootState rs,
                       int B, hipStream_t s);
 void launch_bump_call(uint64_t *call_ctr, hipStream_t s);
-void launch_select(TreeArena ar, RootState rs, LeafBuf lf, SearchParams p, int K, bool vl,
+void launch_select(int game, TreeArena ar, RootState rs, LeafBuf lf, SearchParams p, int K, bool vl,
                    unsigned long long *counters, hipStream_t s);
-void launch_backprop(TreeArena ar, LeafBuf lf, SearchParams p, int K, bool vl, bool fused,
+void launch_backprop(int game, TreeArena ar, LeafBuf lf, SearchParams p, int K, bool vl, bool fused,
                      EvalIn in, unsigned long long *counters, int *err, hipStream_t s);
-void launch_remove_vl(TreeArena ar, LeafBuf lf, SearchParams p, int K, int strideK, hipStream_t s);
+void launch_remove_vl(int game, TreeArena ar, LeafBuf lf, SearchParams p, int K, int strideK, hipStream_t s);
 // Leaves -> evaluator input.  gen_sym: draw symmetry ids from the device generator (else read
 // LeafBuf::sym).  Any output pointer may be nullptr.
-void launch_export(LeafBuf lf, SearchParams p, int n_leaves, bool gen_sym, int8_t *boards,
+void launch_export(int game, LeafBuf lf, SearchParams p, int n_leaves, bool gen_sym, int8_t *boards,
                    uint8_t *valid_mask, float *features, hipStream_t s);
-void launch_prune(TreeArena ar, SearchParams p, const int32_t *actions, int32_t *noise_req,
+void launch_prune(int game, TreeArena ar, SearchParams p, const int32_t *actions, int32_t *noise_req,
                   bool dev_noise, hipStream_t s);
-void launch_apply_noise(TreeArena ar, const int32_t *noise_req, const float *noise, hipStream_t s);
+void launch_apply_noise(int game, TreeArena ar, const int32_t *noise_req, const float *noise, hipStream_t s);
 void launch_reset_masked(TreeArena ar, const uint8_t *mask, hipStream_t s);
-void launch_counts(TreeArena ar, int32_t *counts, hipStream_t s);
-void launch_root_stats(TreeArena ar, float *stats, hipStream_t s);
+void launch_counts(int game, TreeArena ar, int32_t *counts, hipStream_t s);
+void launch_root_stats(int game, TreeArena ar, float *stats, hipStream_t s);
 void launch_init_trees(TreeArena ar, hipStream_t s);
-void launch_rollout(LeafBuf lf, SearchParams p, int B, float *policy, float *d, float *p1w, float *p2w, float *ml,
-                    uint8_t *is_term, hipStream_t s);
-void launch_c4_step(uint64_t *bb0, uint64_t *bb1, int32_t *turns, const int32_t *actions,
-                    uint8_t *done, int32_t *winner, int64_t n, bool reset_finished, hipStream_t s);
+void launch_rollout(int game, LeafBuf lf, SearchParams p, int B, float *policy, float *d, float *p1w, float *p2w,
+                    float *ml, uint8_t *is_term, hipStream_t s);
+void launch_game_step(int game, uint64_t *bb0, uint64_t *bb1, int32_t *turns, const int32_t *actions,
+                      uint8_t *done, int32_t *winner, int64_t n, bool reset_finished, hipStream_t s);
 
 }  // namespace az

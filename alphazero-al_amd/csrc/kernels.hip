@@ -1,10 +1,11 @@
-// kernels.hip - gfx950 kernels of the batched PUCT search (Connect4).
+// kernels.hip - gfx950 kernels of the batched PUCT search, instantiated per game (games.h).
 //
-// Work decomposition: ONE TREE PER 8-LANE GROUP, 8 trees per 64-wide wavefront, one
-// wavefront per workgroup (no LDS, no barriers: all cross-lane traffic is 8-wide shuffles).
-// Lane e of a group owns edge e of whatever node the group is looking at, so a PUCT step is
+// Work decomposition: ONE TREE PER LANE GROUP of G::LANES lanes (Connect4: 8 lanes, 8 trees
+// per 64-wide wavefront; Othello: 64 lanes, one tree per wavefront), one wavefront per
+// workgroup (no LDS, no barriers: all cross-lane traffic is group-wide shuffles).  Lane e of a
+// group owns edge e of whatever node the group is looking at, so a PUCT step is
 //   1 coalesced load of E adjacent 32-byte child records (tree_layout.h)
-//   a 7-term ordered prior sum + 3-step (score, index) max over the group, in registers
+//   an E-term ordered prior sum + log2(LANES)-step (score, index) max over the group
 //   <= 2 dword stores by the winning lane (in-flight count, lazily set flags).
 // Trees are independent (reference: one MCTS object per env under `omp parallel for`,
 // BatchedMCTS.h:107-332), so there is no inter-group or inter-workgroup communication at all.
@@ -13,44 +14,24 @@
 //
 // Memory-ordering rule used throughout: a record that is re-read later in the same kernel is
 // always re-read by the SAME LANE that wrote it (lane = index in its sibling block for
-// selection, lane = depth mod 8 for backup), so plain program order is sufficient.
+// selection, lane = depth mod LANES for backup), so plain program order is sufficient.
 //
 // Arithmetic: compiled with -ffp-contract=off; IEEE fp32 divide and sqrt.  The expression
 // order of MCTS.h:140-234,329-402 and MCTSNode.h:116-133 is kept, and the three fused
 // multiply-adds the compiled reference contains (FPU value, root prior/noise mix, value
-// decay - see oracle/mcts_oracle.c) are explicit fmaf().  No MFMA: this is index/bit work.
+// decay - see oracle/mcts_impl.inc) are explicit fmaf().  No MFMA: this is index/bit work.
 #include "kernels.h"
 
 #include <cstdlib>
 
+#include "games.h"
+
 namespace az {
 namespace {
 
-constexpr int G = LANES_PER_TREE;            // 8
-constexpr int TREES_PER_WAVE = 64 / G;       // 8
 constexpr int WAVE = 64;
 
 // ------------------------------------------------------------------ small device helpers
-
-__device__ __forceinline__ bool c4_has_four(uint64_t b)
-{
-    // Connect4.h:182-203: vertical 1, horizontal 7, diagonals 6 and 8
-    uint64_t t;
-    t = b & (b >> 1); if (t & (t >> 2)) return true;
-    t = b & (b >> 7); if (t & (t >> 14)) return true;
-    t = b & (b >> 6); if (t & (t >> 12)) return true;
-    t = b & (b >> 8); if (t & (t >> 16)) return true;
-    return false;
-}
-
-// result code of a position: -1 not terminal, else 0 draw / 1 P1 wins / 2 P2 wins
-// (check_winner looks at the LAST mover only, then is_full; MCTS.h:279-288,299-319)
-__device__ __forceinline__ int c4_result(uint64_t bb0, uint64_t bb1, int last)
-{
-    if (last >= 0 && c4_has_four(last == 0 ? bb0 : bb1)) return last == 0 ? 1 : 2;
-    if (__popcll(bb0 | bb1) == C4_CELLS) return 0;
-    return -1;
-}
 
 __device__ __forceinline__ float mean_q(int n, float w1, float w2, bool turn_p1)
 {
@@ -90,7 +71,7 @@ struct DevRng {
     {
         const float a = alpha < 1.0f ? alpha + 1.0f : alpha;
         const float d = a - 1.0f / 3.0f, c = 1.0f / sqrtf(9.0f * d);
-        float v, x, u;
+        float v = 1.0f, x, u;
         for (int it = 0; it < 64; ++it) {
             x = normal();
             v = 1.0f + c * x;
@@ -112,69 +93,68 @@ __device__ __forceinline__ void wave_add_counter(unsigned long long *counters, i
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(&counters[which], static_cast<unsigned long long>(v));
 }
 
+template <int L>
 __device__ __forceinline__ HotRec group_bcast(const HotRec &c, int src)
 {
     HotRec r;
-    r.n_visits   = __shfl(c.n_visits, src, G);
-    r.n_inflight = __shfl(c.n_inflight, src, G);
-    r.w_p1       = __shfl(c.w_p1, src, G);
-    r.w_p2       = __shfl(c.w_p2, src, G);
-    r.m_sum      = __shfl(c.m_sum, src, G);
-    r.prior      = __shfl(c.prior, src, G);
-    r.child_off  = __shfl(c.child_off, src, G);
-    r.meta       = static_cast<uint32_t>(__shfl(static_cast<int>(c.meta), src, G));
+    r.n_visits   = __shfl(c.n_visits, src, L);
+    r.n_inflight = __shfl(c.n_inflight, src, L);
+    r.w_p1       = __shfl(c.w_p1, src, L);
+    r.w_p2       = __shfl(c.w_p2, src, L);
+    r.m_sum      = __shfl(c.m_sum, src, L);
+    r.prior      = __shfl(c.prior, src, L);
+    r.child_off  = __shfl(c.child_off, src, L);
+    r.meta       = static_cast<uint32_t>(__shfl(static_cast<int>(c.meta), src, L));
     return r;
+}
+
+__device__ __forceinline__ HotRec empty_rec()
+{
+    HotRec c;
+    c.n_visits = 0; c.n_inflight = 0; c.w_p1 = 0.f; c.w_p2 = 0.f; c.m_sum = 0.f;
+    c.prior = 0.f; c.child_off = -1; c.meta = 0u;
+    return c;
 }
 
 // ------------------------------------------------------------------ import (host entry points)
 
-// Connect4.h:87-129: per column bottom-up until the first empty cell; last mover from parity.
-__global__ void __launch_bounds__(256) k_import(const int8_t *boards, const int32_t *turns,
-                                                RootState rs, int B)
+template <class G>
+__global__ void __launch_bounds__(256) k_import(const int8_t *boards, const int32_t *turns, RootState rs, int B)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B) return;
-    const int8_t *b = boards + static_cast<size_t>(t) * C4_CELLS;
-    uint64_t bb0 = 0, bb1 = 0;
-    int pieces = 0;
-    for (int c = 0; c < C4_COLS; ++c) {
-        int h = c * C4_BITS_PER_COL;
-        for (int r = C4_ROWS - 1; r >= 0; --r) {
-            const int8_t v = b[r * C4_COLS + c];
-            if (v == 0) break;
-            if (v == 1) bb0 |= 1ull << h; else bb1 |= 1ull << h;
-            ++h; ++pieces;
-        }
-    }
-    rs.bb0[t] = bb0; rs.bb1[t] = bb1; rs.turn[t] = turns[t];
-    rs.last[t] = pieces == 0 ? -1 : ((pieces & 1) ? 0 : 1);
+    GameState s;
+    s.turn = turns[t];
+    G::import_cells(boards + static_cast<size_t>(t) * G::CELLS, s);
+    rs.bb0[t] = s.bb0; rs.bb1[t] = s.bb1; rs.turn[t] = s.turn; rs.aux[t] = s.aux;
 }
 
-// device-resident roots: derive the last mover the same way
-__global__ void __launch_bounds__(256) k_set_roots(const uint64_t *bb0, const uint64_t *bb1,
-                                                   const int32_t *turns, RootState rs, int B)
+// device-resident roots: the game's small integer is derived as an import would derive it
+template <class G>
+__global__ void __launch_bounds__(256) k_set_roots(const uint64_t *bb0, const uint64_t *bb1, const int32_t *turns,
+                                                   RootState rs, int B)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B) return;
     const uint64_t a = bb0[t], b = bb1[t];
-    const int pieces = __popcll(a | b);
     rs.bb0[t] = a; rs.bb1[t] = b; rs.turn[t] = turns[t];
-    rs.last[t] = pieces == 0 ? -1 : ((pieces & 1) ? 0 : 1);
+    rs.aux[t] = G::root_aux(a, b);
 }
 
 // ------------------------------------------------------------------ selection
 
 // MCTS.h:242-322 (VL=false) / 443-545 (VL=true) for K consecutive descents of every tree,
 // with compute_fpu (140-156) and select_edge (163-234) evaluated across the group's lanes.
-template <bool VL>
-__global__ void __launch_bounds__(WAVE) k_select(TreeArena ar, RootState rs, LeafBuf lf,
-                                                 SearchParams p, int K, int tpw,
-                                                 unsigned long long *counters)
+template <class G, bool VL>
+__global__ void __launch_bounds__(WAVE) k_select(TreeArena ar, RootState rs, LeafBuf lf, SearchParams p, int K,
+                                                 int tpw, unsigned long long *counters)
 {
+    constexpr int L = G::LANES;
     const int lane = threadIdx.x;
-    const int sub = lane & (G - 1);
-    const int tree = blockIdx.x * tpw + (lane >> 3);
-    const bool live = (lane >> 3) < tpw && tree < ar.B;
+    const int sub = lane % L;
+    const int grp = lane / L;
+    const int tree = blockIdx.x * tpw + grp;
+    const bool live = grp < tpw && tree < ar.B;
     const int t = live ? tree : 0;
 
     HotRec *hot = ar.hot + static_cast<size_t>(t) * ar.S;
@@ -182,18 +162,17 @@ __global__ void __launch_bounds__(WAVE) k_select(TreeArena ar, RootState rs, Lea
     const int root = ar.root[t];
     HotRec rootrec = hot[root];
     int root_infl = rootrec.n_inflight;
-    const uint64_t r_bb0 = rs.bb0[t], r_bb1 = rs.bb1[t];
-    const int r_turn = rs.turn[t], r_last = rs.last[t];
+    GameState rstate;
+    rstate.bb0 = rs.bb0[t]; rstate.bb1 = rs.bb1[t]; rstate.turn = rs.turn[t]; rstate.aux = rs.aux[t];
 
     // state of the descent in progress (uniform across the group)
     int k = 0;
     bool done = !live;
     int cur = root, cur_lane = 0, depth = 0;
     HotRec R = rootrec;
-    uint64_t bb0 = r_bb0, bb1 = r_bb1;
-    int turn = r_turn, last = r_last;
+    GameState st = rstate;
     size_t flat = static_cast<size_t>(t) * K;
-    int32_t *path = lf.path + flat * C4_MAX_PATH;
+    int32_t *path = lf.path + flat * G::MAX_PATH;
     if (!done && sub == 0) path[0] = root;
 
     unsigned n_levels = 0, n_terminal = 0;
@@ -204,9 +183,7 @@ __global__ void __launch_bounds__(WAVE) k_select(TreeArena ar, RootState rs, Lea
             const int E = static_cast<int>((meta & META_NEDGE_MASK) >> META_NEDGE_SHIFT);
             bool stop = !(meta & META_EXPANDED) || (meta & META_TERMINAL) || E == 0;   // MCTS.h:250-258
             int best = -1;
-            HotRec c;
-            c.n_visits = 0; c.n_inflight = 0; c.w_p1 = 0.f; c.w_p2 = 0.f; c.m_sum = 0.f;
-            c.prior = 0.f; c.child_off = -1; c.meta = 0u;
+            HotRec c = empty_rec();
             if (!stop) {
                 const bool has = sub < E;
                 const bool is_root = cur == root;
@@ -223,8 +200,12 @@ __global__ void __launch_bounds__(WAVE) k_select(TreeArena ar, RootState rs, Lea
                 const float pq = mean_q(R.n_visits, R.w_p1, R.w_p2, (meta & META_TURN_P1) != 0);
                 const float seen_term = real ? c.prior : 0.0f;
                 float seen = 0.0f;
+                if (L <= 8) {
 #pragma unroll
-                for (int i = 0; i < C4_ACTIONS; ++i) seen += __shfl(seen_term, i, G);
+                    for (int i = 0; i < L - 1; ++i) seen += __shfl(seen_term, i, L);   // lanes >= E hold 0
+                } else {
+                    for (int i = 0; i < E; ++i) seen += __shfl(seen_term, i, L);
+                }
                 const float scale = (1.0f + pq) / 2.0f;
                 const float eff = p.fpu_reduction * scale;
                 float fpu = fmaf(-eff, sqrtf(seen), pq);
@@ -255,13 +236,7 @@ __global__ void __launch_bounds__(WAVE) k_select(TreeArena ar, RootState rs, Lea
                 }
                 const float u = c_puct * eff_prior * sqrtf(parent_n) /
                                 (1.0f + static_cast<float>(child_total));
-                float m_util = 0.0f;
-                if (real && p.mlh_slope > 0.0f) {           // Connect4.h:231-239
-                    const float v = p.mlh_slope * (child_m - parent_m);
-                    const float lo = -p.mlh_cap, hi = p.mlh_cap;
-                    const float cl = (v < lo) ? lo : ((hi < v) ? hi : v);
-                    m_util = cl * child_q;
-                }
+                const float m_util = real ? G::aux_utility(child_m, parent_m, child_q, p) : 0.0f;
                 const float score = q + u + m_util;
 
                 // strict '>' over ascending edges == max score, lowest index on ties; NaN and
@@ -269,9 +244,9 @@ __global__ void __launch_bounds__(WAVE) k_select(TreeArena ar, RootState rs, Lea
                 float s = (has && score == score) ? score : -INFINITY;
                 int si = sub;
 #pragma unroll
-                for (int o = G / 2; o > 0; o >>= 1) {
-                    const float os = __shfl_xor(s, o, G);
-                    const int oi = __shfl_xor(si, o, G);
+                for (int o = L / 2; o > 0; o >>= 1) {
+                    const float os = __shfl_xor(s, o, L);
+                    const int oi = __shfl_xor(si, o, L);
                     if (os > s || (os == s && oi < si)) { s = os; si = oi; }
                 }
                 best = (s > -INFINITY) ? si : -1;
@@ -281,20 +256,14 @@ __global__ void __launch_bounds__(WAVE) k_select(TreeArena ar, RootState rs, Lea
             if (!stop) {
                 ++n_levels;
                 if (VL && depth == 0) root_infl += p.vl_count;      // MCTS.h:470-475
-                const int action = __shfl(static_cast<int>(c.meta & META_ACTION_MASK), best, G);
-                // Connect4.h:159-172 on bitboards: next free cell of the column
-                const uint64_t colmask = 0x7Full << (C4_BITS_PER_COL * action);
-                const uint64_t mv = (((bb0 | bb1) & colmask) + (1ull << (C4_BITS_PER_COL * action))) & colmask;
-                const int mover = (turn == 1) ? 0 : 1;
-                if (mover == 0) bb0 |= mv; else bb1 |= mv;
-                last = mover;
-                turn = -turn;
-                const int res = c4_result(bb0, bb1, last);
+                const int action = __shfl(static_cast<int>(c.meta & META_ACTION_MASK), best, L);
+                G::step(st, action);
+                const int res = G::result(st);
                 const int child_slot = R.child_off + best;
                 if (sub == best) {
                     uint32_t nm = c.meta;
                     if (!(nm & META_EXISTS))                          // lazy child, MCTS.h:268-275
-                        nm = (nm & ~META_TURN_P1) | META_EXISTS | (turn == 1 ? META_TURN_P1 : 0u);
+                        nm = (nm & ~META_TURN_P1) | META_EXISTS | (st.turn == 1 ? META_TURN_P1 : 0u);
                     if (res >= 0)                                     // MCTS.h:279-288
                         nm = (nm & ~META_RESULT_MASK) | META_TERMINAL |
                              (static_cast<uint32_t>(res) << META_RESULT_SHIFT);
@@ -304,7 +273,7 @@ __global__ void __launch_bounds__(WAVE) k_select(TreeArena ar, RootState rs, Lea
                     }
                     if (nm != c.meta) { c.meta = nm; hot[child_slot].meta = nm; }
                 }
-                R = group_bcast(c, best);
+                R = group_bcast<L>(c, best);
                 cur = child_slot;
                 cur_lane = best;
                 ++depth;
@@ -315,7 +284,7 @@ __global__ void __launch_bounds__(WAVE) k_select(TreeArena ar, RootState rs, Lea
                 bool term = (lm & META_TERMINAL) != 0;
                 int code = static_cast<int>((lm & META_RESULT_MASK) >> META_RESULT_SHIFT);
                 if (!term) {
-                    const int res = c4_result(bb0, bb1, last);
+                    const int res = G::result(st);
                     if (res >= 0) {
                         term = true; code = res;
                         lm = (lm & ~META_RESULT_MASK) | META_TERMINAL |
@@ -329,22 +298,25 @@ __global__ void __launch_bounds__(WAVE) k_select(TreeArena ar, RootState rs, Lea
                 if (VL && depth > 0) fl |= LEAF_VL_APPLIED;
                 if (depth == 0 && !(lm & META_EXPANDED)) fl |= LEAF_ROOT_UNEXPANDED;
                 if (lm & META_EXPANDED) fl |= LEAF_EXPANDED;
+                const int nv = term ? 0 : G::num_valid(st);
                 if (sub == 0) lf.slot[flat] = cur;
-                if (sub == 1) lf.bb0[flat] = bb0;
-                if (sub == 2) lf.bb1[flat] = bb1;
-                if (sub == 3) lf.turn[flat] = turn;
+                if (sub == 1) lf.bb0[flat] = st.bb0;
+                if (sub == 2) lf.bb1[flat] = st.bb1;
+                if (sub == 3) lf.turn[flat] = st.turn;
                 if (sub == 4) lf.flags[flat] = fl;
                 if (sub == 5) lf.path_len[flat] = depth + 1;
+                if (sub == 6) lf.aux[flat] = st.aux;
+                if (sub == 7) lf.nvalid[flat] = static_cast<uint8_t>(nv);
 
                 ++k;
                 if (k == K) {
                     done = true;
                 } else {
                     ++flat;
-                    path += C4_MAX_PATH;
+                    path += G::MAX_PATH;
                     cur = root; cur_lane = 0; depth = 0;
                     R = rootrec; R.n_inflight = root_infl;
-                    bb0 = r_bb0; bb1 = r_bb1; turn = r_turn; last = r_last;
+                    st = rstate;
                     if (sub == 0) path[0] = root;
                 }
             }
@@ -362,30 +334,31 @@ __global__ void __launch_bounds__(WAVE) k_select(TreeArena ar, RootState rs, Lea
 // ------------------------------------------------------------------ virtual-loss removal
 
 // MCTS.h:561-581: every node of a recorded path (root included) loses vl_count in-flight
-// visits once; clearing the flag makes the call idempotent.  Lane j handles depth j.
-__device__ __forceinline__ void remove_vl_of_tree(HotRec *hot, LeafBuf lf, size_t flat0, int K,
-                                                  int vl, int sub)
+// visits once; clearing the flag makes the call idempotent.  Lane j handles depth j mod LANES.
+template <class G>
+__device__ __forceinline__ void remove_vl_of_tree(HotRec *hot, LeafBuf lf, size_t flat0, int K, int vl, int sub)
 {
     for (int k = 0; k < K; ++k) {
         const size_t flat = flat0 + k;
         const uint8_t fl = lf.flags[flat];
         if (fl & LEAF_VL_APPLIED) {
-            const int L = lf.path_len[flat];
-            const int32_t *path = lf.path + flat * C4_MAX_PATH;
-            for (int j = sub; j < L; j += G) hot[path[j]].n_inflight -= vl;
+            const int len = lf.path_len[flat];
+            const int32_t *path = lf.path + flat * G::MAX_PATH;
+            for (int j = sub; j < len; j += G::LANES) hot[path[j]].n_inflight -= vl;
             if (sub == 0) lf.flags[flat] = fl & static_cast<uint8_t>(~LEAF_VL_APPLIED);
         }
     }
 }
 
-__global__ void __launch_bounds__(WAVE) k_remove_vl(TreeArena ar, LeafBuf lf, SearchParams p,
-                                                    int K, int strideK)
+template <class G>
+__global__ void __launch_bounds__(WAVE) k_remove_vl(TreeArena ar, LeafBuf lf, SearchParams p, int K, int strideK)
 {
-    const int sub = threadIdx.x & (G - 1);
-    const int tree = blockIdx.x * TREES_PER_WAVE + (threadIdx.x >> 3);
+    constexpr int L = G::LANES;
+    const int sub = threadIdx.x % L;
+    const int tree = blockIdx.x * (WAVE / L) + threadIdx.x / L;
     if (tree >= ar.B) return;
-    remove_vl_of_tree(ar.hot + static_cast<size_t>(tree) * ar.S, lf,
-                      static_cast<size_t>(tree) * strideK, K, p.vl_count, sub);
+    remove_vl_of_tree<G>(ar.hot + static_cast<size_t>(tree) * ar.S, lf, static_cast<size_t>(tree) * strideK, K,
+                         p.vl_count, sub);
 }
 
 // ------------------------------------------------------------------ expansion + backup
@@ -394,14 +367,17 @@ __global__ void __launch_bounds__(WAVE) k_remove_vl(TreeArena ar, LeafBuf lf, Se
 // k = 0..K-1 expand_leaf (MCTS.h:329-375) and propagate (MCTS.h:381-402).
 // FUSED=true takes the evaluator's raw outputs (relative WDL) and the leaf's own flags, i.e.
 // it also does what MCTS_cpp.py:275-297 does between the two native calls.
-template <bool VL, bool FUSED>
+template <class G, bool VL, bool FUSED>
 __global__ void __launch_bounds__(WAVE) k_backprop(TreeArena ar, LeafBuf lf, SearchParams p, int K, int tpw,
                                                    EvalIn in, unsigned long long *counters, int *err)
 {
+    constexpr int L = G::LANES;
+    constexpr int A = G::ACTIONS;
     const int lane = threadIdx.x;
-    const int sub = lane & (G - 1);
-    const int tree = blockIdx.x * tpw + (lane >> 3);
-    const bool live = (lane >> 3) < tpw && tree < ar.B;
+    const int sub = lane % L;
+    const int grp = lane / L;
+    const int tree = blockIdx.x * tpw + grp;
+    const bool live = grp < tpw && tree < ar.B;
     const int t = live ? tree : 0;
     HotRec *hot = ar.hot + static_cast<size_t>(t) * ar.S;
     ColdRec *cold = ar.cold + static_cast<size_t>(t) * ar.S;
@@ -409,20 +385,20 @@ __global__ void __launch_bounds__(WAVE) k_backprop(TreeArena ar, LeafBuf lf, Sea
     unsigned n_exp = 0, n_dup = 0, n_backup = 0;
 
     if (live) {
-        if (VL) remove_vl_of_tree(hot, lf, flat0, K, p.vl_count, sub);
+        if (VL) remove_vl_of_tree<G>(hot, lf, flat0, K, p.vl_count, sub);
 
         int used = ar.used[t];
         const int used0 = used;
         for (int k = 0; k < K; ++k) {
             const size_t flat = flat0 + k;
-            const int L = lf.path_len[flat];
-            if (L <= 0) continue;                                   // MCTS.h:409,599
+            const int len = lf.path_len[flat];
+            if (len <= 0) continue;                                 // MCTS.h:409,599
             const int leaf = lf.slot[flat];
-            const uint64_t occ = lf.bb0[flat] | lf.bb1[flat];
-            const int lturn = lf.turn[flat];
+            GameState ls;
+            ls.bb0 = lf.bb0[flat]; ls.bb1 = lf.bb1[flat]; ls.turn = lf.turn[flat]; ls.aux = lf.aux[flat];
             const uint8_t lflags = lf.flags[flat];
-            const int32_t *path = lf.path + flat * C4_MAX_PATH;
-            const int owner = (L - 1) & (G - 1);
+            const int32_t *path = lf.path + flat * G::MAX_PATH;
+            const int owner = (len - 1) % L;
 
             bool term;
             float wd, w1, w2, ml;
@@ -435,49 +411,48 @@ __global__ void __launch_bounds__(WAVE) k_backprop(TreeArena ar, LeafBuf lf, Sea
                 } else {                                            // MCTS_cpp.py:23-30
                     const float *r = in.wdl_rel + flat * 3;
                     wd = r[0];
-                    w1 = (lturn == 1) ? r[1] : r[2];
-                    w2 = (lturn == 1) ? r[2] : r[1];
+                    w1 = (ls.turn == 1) ? r[1] : r[2];
+                    w2 = (ls.turn == 1) ? r[2] : r[1];
                     ml = in.moves_left[flat];
                 }
             } else {
                 term = in.is_term[flat] != 0;
                 wd = in.d[flat]; w1 = in.p1w[flat]; w2 = in.p2w[flat];
-                ml = term ? 0.0f : in.moves_left[flat];             // terminal_aux == 0, Connect4.h:226-229
+                ml = in.moves_left[flat];
             }
+            if (term) ml = G::terminal_aux(ls, p);                  // MCTS.h:412,608
 
             if (!term) {
                 // is_expanded must be the CURRENT value (an earlier k of this call may have
                 // expanded the same leaf, MCTS.h:601-607): read by the lane that writes it.
                 uint32_t lm = 0;
                 if (sub == owner) lm = hot[leaf].meta;
-                lm = static_cast<uint32_t>(__shfl(static_cast<int>(lm), owner, G));
+                lm = static_cast<uint32_t>(__shfl(static_cast<int>(lm), owner, L));
                 if (VL && (lm & META_EXPANDED)) {
                     ++n_dup;
                 } else {
-                    // expand_leaf: valid columns ascending (Connect4.h:209-218)
-                    int nv = 0, my_action = -1;
-#pragma unroll
-                    for (int c = 0; c < C4_COLS; ++c) {
-                        if (!((occ >> (c * C4_BITS_PER_COL + C4_ROWS - 1)) & 1ull)) {
-                            if (nv == sub) my_action = c;
-                            ++nv;
-                        }
-                    }
-                    const int s = in.sym ? in.sym[VL ? flat : static_cast<size_t>(t)] : lf.sym[flat];
-                    float my_pol = 0.0f;                            // Connect4.h:288-294
-                    if (my_action >= 0) my_pol = in.policy[flat * C4_ACTIONS + (s ? C4_COLS - 1 - my_action : my_action)];
+                    // expand_leaf: legal moves in edge order
+                    const int nv = G::num_valid(ls);
+                    const int my_action = sub < nv ? G::nth_valid(ls, sub) : -1;
+                    const int s = in.sym ? in.sym[flat] : lf.sym[flat];
+                    float my_pol = 0.0f;
+                    if (my_action >= 0) my_pol = in.policy[flat * A + G::policy_index(s, my_action)];
                     float psum = 0.0f;
+                    if (L <= 8) {
 #pragma unroll
-                    for (int i = 0; i < C4_ACTIONS; ++i) psum += __shfl(my_pol, i, G);
+                        for (int i = 0; i < L - 1; ++i) psum += __shfl(my_pol, i, L);
+                    } else {
+                        for (int i = 0; i < nv; ++i) psum += __shfl(my_pol, i, L);
+                    }
                     const float prior = my_pol / (psum + 1e-8f);    // MCTS.h:370
                     if (static_cast<int64_t>(used) + nv > ar.S) {
                         if (sub == 0) atomicExch(err, 1);
                     } else {
-                        const bool root_leaf = (L == 1);            // leaf.parent == -1, MCTS.h:349
+                        const bool root_leaf = (len == 1);          // leaf.parent == -1, MCTS.h:349
                         float noise = 0.0f;
                         if (root_leaf && p.alpha > 0.0f && sub < nv) {
                             if (in.root_noise) {
-                                noise = in.root_noise[static_cast<size_t>(t) * C4_ACTIONS + sub];
+                                noise = in.root_noise[static_cast<size_t>(t) * A + sub];
                             } else {
                                 DevRng g(p.seed, *p.call_ptr, static_cast<uint64_t>(t), static_cast<uint64_t>(sub) + 16);
                                 noise = g.gamma(p.alpha);
@@ -485,14 +460,12 @@ __global__ void __launch_bounds__(WAVE) k_backprop(TreeArena ar, LeafBuf lf, Sea
                         }
                         if (root_leaf && p.alpha > 0.0f && !in.root_noise) {
                             float sum = 0.0f;
-#pragma unroll
-                            for (int i = 0; i < C4_ACTIONS; ++i) sum += __shfl(sub < nv ? noise : 0.0f, i, G);
+                            for (int i = 0; i < nv; ++i) sum += __shfl(noise, i, L);
                             noise = noise * (1.0f / (sum + 1e-8f));
                         }
                         if (sub < nv) {
-                            HotRec h;
-                            h.n_visits = 0; h.n_inflight = 0; h.w_p1 = 0.f; h.w_p2 = 0.f; h.m_sum = 0.f;
-                            h.prior = prior; h.child_off = -1; h.meta = static_cast<uint32_t>(my_action);
+                            HotRec h = empty_rec();
+                            h.prior = prior; h.meta = static_cast<uint32_t>(my_action);
                             hot[used + sub] = h;
                             ColdRec cr;
                             cr.w_draw = 0.f; cr.noise = noise; cr.parent = leaf; cr.reserved = 0;
@@ -511,14 +484,16 @@ __global__ void __launch_bounds__(WAVE) k_backprop(TreeArena ar, LeafBuf lf, Sea
             }
 
             // propagate, lane j <-> depth j (root = 0): the node `dist` levels above the leaf
-            // receives ml + dist (sequential +1) and the value decayed dist times
-            for (int j = sub; j < L; j += G) {
-                const int dist = L - 1 - j;
+            // receives the auxiliary value after `dist` per-ply steps (+1 or sign flip) and the
+            // value decayed dist times
+            for (int j = sub; j < len; j += L) {
+                const int dist = len - 1 - j;
                 float a = wd, b = w1, c = w2, mm = ml;
                 const float g = p.value_decay;
                 const float cst = (1.0f - g) * (1.0f / 3.0f);
                 for (int i = 0; i < dist; ++i) {
-                    mm += 1.0f;
+                    if (G::AUX_PLUS_ONE) mm += 1.0f;
+                    if (G::AUX_NEGATE) mm = -mm;
                     if (g < 1.0f) { a = fmaf(a, g, cst); b = fmaf(b, g, cst); c = fmaf(c, g, cst); }
                 }
                 const int slot = path[j];
@@ -542,43 +517,40 @@ __global__ void __launch_bounds__(WAVE) k_backprop(TreeArena ar, LeafBuf lf, Sea
 // BatchedMCTS.h:141-169 / 254-283 (symmetry, grid export, valid mask) and MCTS_cpp.py:15-20
 // (relative feature planes).  One thread per (leaf, cell); cells of a leaf are contiguous so
 // every plane row is a coalesced store.
-__global__ void __launch_bounds__(256) k_export(LeafBuf lf, SearchParams p, int n_leaves,
-                                                int gen_sym, int8_t *boards, uint8_t *valid_mask,
-                                                float *features)
+template <class G>
+__global__ void __launch_bounds__(256) k_export(LeafBuf lf, SearchParams p, int n_leaves, int gen_sym,
+                                                int8_t *boards, uint8_t *valid_mask, float *features)
 {
+    constexpr int CELLS = G::CELLS, A = G::ACTIONS;
     const int64_t gid = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    const int64_t leaf = gid / C4_CELLS;
-    const int cell = static_cast<int>(gid - leaf * C4_CELLS);
+    const int64_t leaf = gid / CELLS;
+    const int cell = static_cast<int>(gid - leaf * CELLS);
     if (leaf >= n_leaves) return;
-    const uint64_t bb0 = lf.bb0[leaf], bb1 = lf.bb1[leaf];
-    const int turn = lf.turn[leaf];
+    GameState s;
+    s.bb0 = lf.bb0[leaf]; s.bb1 = lf.bb1[leaf]; s.turn = lf.turn[leaf]; s.aux = lf.aux[leaf];
     const bool term = (lf.flags[leaf] & LEAF_TERMINAL) != 0;
     int sym;
     if (gen_sym) {
         sym = 0;
         if (!term && p.use_symmetry) {
             DevRng g(p.seed, *p.call_ptr, static_cast<uint64_t>(leaf), 7);
-            sym = static_cast<int>(g.next() >> 31);
+            sym = G::sym_of_choice(static_cast<int>((static_cast<uint64_t>(g.next()) * G::SYM_CHOICES) >> 32));
         }
         if (cell == 0) lf.sym[leaf] = sym;
     } else {
         sym = lf.sym[leaf];
     }
-    const int r = cell / C4_COLS, c = cell - r * C4_COLS;
-    const int cs = sym ? (C4_COLS - 1 - c) : c;                       // Connect4.h:249-280
-    const int bit = cs * C4_BITS_PER_COL + (C4_ROWS - 1 - r);
-    const int v = ((bb0 >> bit) & 1ull) ? 1 : (((bb1 >> bit) & 1ull) ? -1 : 0);
-    if (boards) boards[leaf * C4_CELLS + cell] = static_cast<int8_t>(v);
+    const int v = G::cell_value(s, sym, cell);
+    if (boards) boards[leaf * CELLS + cell] = static_cast<int8_t>(v);
     if (features) {
-        float *f = features + leaf * (3 * C4_CELLS) + cell;
-        f[0] = (v == turn) ? 1.0f : 0.0f;
-        f[C4_CELLS] = (v == -turn) ? 1.0f : 0.0f;
-        f[2 * C4_CELLS] = static_cast<float>(turn);
+        float *f = features + leaf * (3 * CELLS) + cell;
+        f[0] = (v == s.turn) ? 1.0f : 0.0f;
+        f[CELLS] = (v == -s.turn) ? 1.0f : 0.0f;
+        f[2 * CELLS] = static_cast<float>(s.turn);
     }
-    if (valid_mask && cell < C4_ACTIONS) {
-        const int cc = sym ? (C4_COLS - 1 - cell) : cell;
-        const bool open = !(((bb0 | bb1) >> (cc * C4_BITS_PER_COL + C4_ROWS - 1)) & 1ull);
-        valid_mask[leaf * C4_ACTIONS + cell] = (!term && open) ? 1 : 0;
+    if (valid_mask) {
+        for (int a = cell; a < A; a += CELLS)
+            valid_mask[leaf * A + a] = (!term && G::valid_in_frame(s, sym, a)) ? 1 : 0;
     }
 }
 
@@ -586,9 +558,8 @@ __global__ void __launch_bounds__(256) k_export(LeafBuf lf, SearchParams p, int 
 
 __device__ __forceinline__ void write_fresh_root(HotRec *hot, ColdRec *cold)
 {
-    HotRec h;                                                          // MCTS.h:77-82
-    h.n_visits = 0; h.n_inflight = 0; h.w_p1 = 0.f; h.w_p2 = 0.f; h.m_sum = 0.f; h.prior = 0.f;
-    h.child_off = -1; h.meta = META_TURN_P1 | META_EXISTS;
+    HotRec h = empty_rec();                                            // MCTS.h:77-82
+    h.meta = META_TURN_P1 | META_EXISTS;
     hot[0] = h;
     ColdRec c;
     c.w_draw = 0.f; c.noise = 0.f; c.parent = -1; c.reserved = 0;
@@ -613,15 +584,26 @@ __global__ void __launch_bounds__(256) k_reset_masked(TreeArena ar, const uint8_
     ar.used[t] = 1;
 }
 
+// group-local ballot: bit i set <=> lane i of this lane group votes true
+template <int L>
+__device__ __forceinline__ unsigned long long group_ballot(bool pred, int lane)
+{
+    const unsigned long long bal = __ballot(pred);
+    if (L == 64) return bal;
+    return (bal >> (lane - lane % L)) & ((1ull << L) - 1ull);
+}
+
 // MCTS.h:90-132: re-root at the child reached by `action` if the reference would have
 // allocated it, else reset.  noise_req[t] = number of root edges that need fresh Dirichlet
 // noise (0 if none) for the host generator; with dev_noise the noise is drawn here.
+template <class G>
 __global__ void __launch_bounds__(WAVE) k_prune(TreeArena ar, SearchParams p, const int32_t *actions,
                                                 int32_t *noise_req, int dev_noise)
 {
+    constexpr int L = G::LANES;
     const int lane = threadIdx.x;
-    const int sub = lane & (G - 1);
-    const int tree = blockIdx.x * TREES_PER_WAVE + (lane >> 3);
+    const int sub = lane % L;
+    const int tree = blockIdx.x * (WAVE / L) + lane / L;
     const bool live = tree < ar.B;
     const int t = live ? tree : 0;
     HotRec *hot = ar.hot + static_cast<size_t>(t) * ar.S;
@@ -630,21 +612,19 @@ __global__ void __launch_bounds__(WAVE) k_prune(TreeArena ar, SearchParams p, co
     const HotRec R = hot[root];
     const int action = actions[t];
     const int E = static_cast<int>((R.meta & META_NEDGE_MASK) >> META_NEDGE_SHIFT);
-    HotRec c;
-    c.meta = 0; c.child_off = -1; c.n_visits = 0; c.n_inflight = 0; c.w_p1 = c.w_p2 = c.m_sum = c.prior = 0.f;
+    HotRec c = empty_rec();
     bool match = false;
     if (live && (R.meta & META_EXPANDED) && sub < E) {
         c = hot[R.child_off + sub];
         match = static_cast<int>(c.meta & META_ACTION_MASK) == action && (c.meta & META_EXISTS);
     }
-    const unsigned long long bal = __ballot(match);
-    const unsigned grp = static_cast<unsigned>((bal >> (lane & ~(G - 1))) & 0xffu);
+    const unsigned long long grpb = group_ballot<L>(match, lane);
     if (!live) return;
-    if (grp) {
-        const int e = __ffs(static_cast<int>(grp)) - 1;
+    if (grpb) {
+        const int e = __ffsll(grpb) - 1;
         const int new_root = R.child_off + e;
-        const uint32_t nm = static_cast<uint32_t>(__shfl(static_cast<int>(c.meta), e, G));
-        const int noff = __shfl(c.child_off, e, G);
+        const uint32_t nm = static_cast<uint32_t>(__shfl(static_cast<int>(c.meta), e, L));
+        const int noff = __shfl(c.child_off, e, L);
         const int nE = (nm & META_EXPANDED) ? static_cast<int>((nm & META_NEDGE_MASK) >> META_NEDGE_SHIFT) : 0;
         if (sub == 0) { ar.root[t] = new_root; cold[new_root].parent = -1; }
         const int want = (p.alpha > 0.0f) ? nE : 0;                  // apply_root_noise
@@ -653,12 +633,11 @@ __global__ void __launch_bounds__(WAVE) k_prune(TreeArena ar, SearchParams p, co
         } else if (want > 0) {
             float g = 0.0f;
             if (sub < want) {
-                DevRng rng(p.seed, *p.call_ptr, static_cast<uint64_t>(t), static_cast<uint64_t>(sub) + 32);
+                DevRng rng(p.seed, *p.call_ptr, static_cast<uint64_t>(t), static_cast<uint64_t>(sub) + 128);
                 g = rng.gamma(p.alpha);
             }
             float sum = 0.0f;
-#pragma unroll
-            for (int i = 0; i < C4_ACTIONS; ++i) sum += __shfl(g, i, G);
+            for (int i = 0; i < want; ++i) sum += __shfl(g, i, L);
             if (sub < want) cold[noff + sub].noise = g * (1.0f / (sum + 1e-8f));
         }
     } else {
@@ -671,30 +650,34 @@ __global__ void __launch_bounds__(WAVE) k_prune(TreeArena ar, SearchParams p, co
     }
 }
 
-__global__ void __launch_bounds__(WAVE) k_apply_noise(TreeArena ar, const int32_t *noise_req,
-                                                      const float *noise)
+template <class G>
+__global__ void __launch_bounds__(WAVE) k_apply_noise(TreeArena ar, const int32_t *noise_req, const float *noise)
 {
-    const int sub = threadIdx.x & (G - 1);
-    const int tree = blockIdx.x * TREES_PER_WAVE + (threadIdx.x >> 3);
+    constexpr int L = G::LANES;
+    const int sub = threadIdx.x % L;
+    const int tree = blockIdx.x * (WAVE / L) + threadIdx.x / L;
     if (tree >= ar.B) return;
     const int nv = noise_req[tree];
     if (nv <= 0 || sub >= nv) return;
     const HotRec *hot = ar.hot + static_cast<size_t>(tree) * ar.S;
     ColdRec *cold = ar.cold + static_cast<size_t>(tree) * ar.S;
     const int off = hot[ar.root[tree]].child_off;
-    cold[off + sub].noise = noise[static_cast<size_t>(tree) * C4_ACTIONS + sub];
+    cold[off + sub].noise = noise[static_cast<size_t>(tree) * G::ACTIONS + sub];
 }
 
 // ------------------------------------------------------------------ root queries
 
-// get_counts (MCTS.h:617-630) and get_root_stats (MCTS.h:637-673).  Lane a gathers the edge
-// whose action is a through shuffles, then writes its own output slot.
-template <bool STATS>
+// get_counts (MCTS.h:617-630) and get_root_stats (MCTS.h:637-673).  Lane e scatters the values
+// of edge e into the slot of its action; the slots of actions that have no edge are zeroed by
+// other writes to DISJOINT addresses (presence comes from a group ballot), so no two lanes
+// ever store to the same word.
+template <class G, bool STATS>
 __global__ void __launch_bounds__(WAVE) k_root_query(TreeArena ar, int32_t *counts, float *stats)
 {
+    constexpr int L = G::LANES, A = G::ACTIONS;
     const int lane = threadIdx.x;
-    const int sub = lane & (G - 1);
-    const int tree = blockIdx.x * TREES_PER_WAVE + (lane >> 3);
+    const int sub = lane % L;
+    const int tree = blockIdx.x * (WAVE / L) + lane / L;
     const bool live = tree < ar.B;
     const int t = live ? tree : 0;
     const HotRec *hot = ar.hot + static_cast<size_t>(t) * ar.S;
@@ -703,70 +686,72 @@ __global__ void __launch_bounds__(WAVE) k_root_query(TreeArena ar, int32_t *coun
     const HotRec R = hot[root];
     const bool expanded = (R.meta & META_EXPANDED) != 0;
     const int E = expanded ? static_cast<int>((R.meta & META_NEDGE_MASK) >> META_NEDGE_SHIFT) : 0;
-    HotRec c;
-    c.meta = 0; c.child_off = -1; c.n_visits = 0; c.n_inflight = 0; c.w_p1 = c.w_p2 = c.m_sum = c.prior = 0.f;
+    HotRec c = empty_rec();
     ColdRec cc;
     cc.w_draw = 0.f; cc.noise = 0.f; cc.parent = -1; cc.reserved = 0;
-    if (sub < E) {
+    const bool has = live && sub < E;
+    if (has) {
         c = hot[R.child_off + sub];
         if (STATS) cc = cold[R.child_off + sub];
     }
-    const bool exists = sub < E && (c.meta & META_EXISTS);
-    // per-edge values
-    float e_vals[8];
-    e_vals[0] = exists ? static_cast<float>(c.n_visits) : 0.0f;
-    int e_cnt = exists ? c.n_visits : 0;
-    if (STATS) {
-        const float inv = (exists && c.n_visits != 0) ? 1.0f / static_cast<float>(c.n_visits) : 0.0f;
-        const bool has = exists && c.n_visits != 0;
-        const float u3 = 1.f / 3;
-        const float d = exists ? (has ? cc.w_draw * inv : u3) : 0.0f;
-        const float p1 = exists ? (has ? c.w_p1 * inv : u3) : 0.0f;
-        const float p2 = exists ? (has ? c.w_p2 * inv : u3) : 0.0f;
-        e_vals[1] = exists ? ((c.meta & META_TURN_P1) ? (p1 - p2) : (p2 - p1)) : 0.0f;
-        e_vals[2] = sub < E ? c.prior : 0.0f;
-        e_vals[3] = sub < E ? cc.noise : 0.0f;
-        e_vals[4] = exists ? mean_m(c.n_visits, c.m_sum) : 0.0f;
-        e_vals[5] = d; e_vals[6] = p1; e_vals[7] = p2;
+    const int my_action = has ? static_cast<int>(c.meta & META_ACTION_MASK) : -1;
+    // which actions own an edge: squares/columns 0..63 in a mask, action 64 (pass) separately
+    const unsigned long long low = group_ballot<L>(has && my_action < 64, lane);
+    unsigned long long present = 0;
+    for (unsigned long long m = low; m; m &= m - 1) {
+        const int e = __ffsll(m) - 1;
+        present |= 1ull << __shfl(my_action, e, L);
     }
-    const int my_action = sub < E ? static_cast<int>(c.meta & META_ACTION_MASK) : -1;
-    // gather by action
-    float o_vals[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int o_cnt = 0;
-#pragma unroll
-    for (int e = 0; e < C4_ACTIONS; ++e) {
-        const int a = __shfl(my_action, e, G);
-        const int cn = __shfl(e_cnt, e, G);
-        if (a == sub) o_cnt = cn;
-        if (STATS) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float v = __shfl(e_vals[q], e, G);
-                if (a == sub) o_vals[q] = v;
-            }
-        }
-    }
-    if (!live || sub >= C4_ACTIONS) return;
+    const bool pass_present = group_ballot<L>(has && my_action == 64, lane) != 0;
+    if (!live) return;
+    const bool exists = has && (c.meta & META_EXISTS);
+
     if (!STATS) {
-        counts[static_cast<size_t>(t) * C4_ACTIONS + sub] = o_cnt;
-    } else {
-        float *o = stats + static_cast<size_t>(t) * C4_STATS;
-        if (sub == 0) {
-            const ColdRec rc = cold[root];
-            const bool has = R.n_visits != 0;
-            const float inv = has ? 1.0f / static_cast<float>(R.n_visits) : 0.0f;
-            const float u3 = 1.f / 3;
-            const float d = has ? rc.w_draw * inv : u3;
-            const float p1 = has ? R.w_p1 * inv : u3;
-            const float p2 = has ? R.w_p2 * inv : u3;
-            o[0] = static_cast<float>(R.n_visits);
-            o[1] = (R.meta & META_TURN_P1) ? (p1 - p2) : (p2 - p1);
-            o[2] = mean_m(R.n_visits, R.m_sum);
-            o[3] = d; o[4] = p1; o[5] = p2;
+        int32_t *o = counts + static_cast<size_t>(t) * A;
+        if (has) o[my_action] = exists ? c.n_visits : 0;
+        for (int a = sub; a < A; a += L) {
+            const bool pres = a < 64 ? ((present >> a) & 1ull) : pass_present;
+            if (!pres) o[a] = 0;
         }
-        float *slot = o + 6 + sub * 8;
+        return;
+    }
+    float *o = stats + static_cast<size_t>(t) * G::STATS;
+    const float u3 = 1.f / 3;
+    if (sub == 0) {
+        const ColdRec rc = cold[root];
+        const bool hv = R.n_visits != 0;
+        const float inv = hv ? 1.0f / static_cast<float>(R.n_visits) : 0.0f;
+        const float d = hv ? rc.w_draw * inv : u3;
+        const float p1 = hv ? R.w_p1 * inv : u3;
+        const float p2 = hv ? R.w_p2 * inv : u3;
+        o[0] = static_cast<float>(R.n_visits);
+        o[1] = (R.meta & META_TURN_P1) ? (p1 - p2) : (p2 - p1);
+        o[2] = mean_m(R.n_visits, R.m_sum);
+        o[3] = d; o[4] = p1; o[5] = p2;
+    }
+    if (has) {
+        float *slot = o + 6 + my_action * 8;
+        const bool hv = exists && c.n_visits != 0;
+        const float inv = hv ? 1.0f / static_cast<float>(c.n_visits) : 0.0f;
+        const float d = exists ? (hv ? cc.w_draw * inv : u3) : 0.0f;
+        const float p1 = exists ? (hv ? c.w_p1 * inv : u3) : 0.0f;
+        const float p2 = exists ? (hv ? c.w_p2 * inv : u3) : 0.0f;
+        float mm = exists ? mean_m(c.n_visits, c.m_sum) : 0.0f;
+        if (G::AUX_NEGATE && exists) mm = -mm;                        // MCTS.h:662-664
+        slot[0] = exists ? static_cast<float>(c.n_visits) : 0.0f;
+        slot[1] = exists ? ((c.meta & META_TURN_P1) ? (p1 - p2) : (p2 - p1)) : 0.0f;
+        slot[2] = c.prior;
+        slot[3] = cc.noise;
+        slot[4] = mm;
+        slot[5] = d; slot[6] = p1; slot[7] = p2;
+    }
+    for (int a = sub; a < A; a += L) {
+        const bool pres = a < 64 ? ((present >> a) & 1ull) : pass_present;
+        if (!pres) {
+            float *slot = o + 6 + a * 8;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) slot[q] = o_vals[q];
+            for (int q = 0; q < 8; ++q) slot[q] = 0.0f;
+        }
     }
 }
 
@@ -774,7 +759,8 @@ __global__ void __launch_bounds__(WAVE) k_root_query(TreeArena ar, int32_t *coun
 
 // RolloutEvaluator::evaluate_single (RolloutEvaluator.h:23-48) for the leaves of one plain
 // selection: uniform policy (all ones), value = result of a uniformly random playout from
-// the leaf, moves_left 0.  One thread per tree; moves come from the device generator.
+// the leaf, auxiliary value 0.  One thread per tree; moves come from the device generator.
+template <class G>
 __global__ void __launch_bounds__(256) k_rollout(LeafBuf lf, SearchParams p, int B, float *policy, float *d,
                                                  float *p1w, float *p2w, float *ml, uint8_t *is_term)
 {
@@ -784,147 +770,148 @@ __global__ void __launch_bounds__(256) k_rollout(LeafBuf lf, SearchParams p, int
     const bool term = (fl & LEAF_TERMINAL) != 0;
     int code = (fl >> LEAF_RESULT_SHIFT) & 3;
     if (!term) {
-        uint64_t bb0 = lf.bb0[t], bb1 = lf.bb1[t];
-        int turn = lf.turn[t];
-        // last mover of the leaf position: parity of the piece count, as import_board derives it
-        const int pieces = __popcll(bb0 | bb1);
-        int last = pieces == 0 ? -1 : ((pieces & 1) ? 0 : 1);
+        GameState s;
+        s.bb0 = lf.bb0[t]; s.bb1 = lf.bb1[t]; s.turn = lf.turn[t]; s.aux = lf.aux[t];
         DevRng g(p.seed, *p.call_ptr, static_cast<uint64_t>(t), 3);
-        int res = c4_result(bb0, bb1, last);
-        while (res < 0) {
-            const uint64_t occ = bb0 | bb1;
-            int cols[C4_COLS], nv = 0;
-#pragma unroll
-            for (int c = 0; c < C4_COLS; ++c)
-                if (!((occ >> (c * C4_BITS_PER_COL + C4_ROWS - 1)) & 1ull)) cols[nv++] = c;
-            const int a = cols[static_cast<int>((static_cast<uint64_t>(g.next()) * static_cast<uint64_t>(nv)) >> 32)];
-            const uint64_t colmask = 0x7Full << (C4_BITS_PER_COL * a);
-            const uint64_t mv = ((occ & colmask) + (1ull << (C4_BITS_PER_COL * a))) & colmask;
-            const int mover = (turn == 1) ? 0 : 1;
-            if (mover == 0) bb0 |= mv; else bb1 |= mv;
-            last = mover;
-            turn = -turn;
-            res = c4_result(bb0, bb1, last);
+        int res = G::result(s);
+        for (int ply = 0; res < 0 && ply < 4 * G::CELLS; ++ply) {
+            const int nv = G::num_valid(s);
+            if (nv <= 0) break;
+            const int pick = static_cast<int>((static_cast<uint64_t>(g.next()) * static_cast<uint64_t>(nv)) >> 32);
+            G::step(s, G::nth_valid(s, pick));
+            res = G::result(s);
         }
-        code = res;
+        code = res < 0 ? 0 : res;
     }
     is_term[t] = term ? 1 : 0;
     d[t] = code == 0 ? 1.0f : 0.0f;
     p1w[t] = code == 1 ? 1.0f : 0.0f;
     p2w[t] = code == 2 ? 1.0f : 0.0f;
     ml[t] = 0.0f;
-#pragma unroll
-    for (int a = 0; a < C4_ACTIONS; ++a) policy[static_cast<size_t>(t) * C4_ACTIONS + a] = term ? 0.0f : 1.0f;
+    for (int a = 0; a < G::ACTIONS; ++a) policy[static_cast<size_t>(t) * G::ACTIONS + a] = term ? 0.0f : 1.0f;
 }
 
 // ------------------------------------------------------------------ batched game step
 
-// Connect4.h:159-172 (step) + 182-203 / 221-224 (result) on HBM-resident positions
-__global__ void __launch_bounds__(256) k_c4_step(uint64_t *bb0, uint64_t *bb1, int32_t *turns,
-                                                 const int32_t *actions, uint8_t *done,
-                                                 int32_t *winner, int64_t n, int reset_finished)
+// step + result (Connect4.h:159-203 / Othello.h:206-258) on HBM-resident positions
+template <class G>
+__global__ void __launch_bounds__(256) k_game_step(uint64_t *bb0, uint64_t *bb1, int32_t *turns,
+                                                   const int32_t *actions, uint8_t *done, int32_t *winner,
+                                                   int64_t n, int reset_finished)
 {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int a = actions[i];
-    if (a < 0 || a >= C4_COLS) { done[i] = 0; winner[i] = 0; return; }
-    uint64_t b0 = bb0[i], b1 = bb1[i];
-    int turn = turns[i];
-    const uint64_t colmask = 0x7Full << (C4_BITS_PER_COL * a);
-    const uint64_t mv = (((b0 | b1) & colmask) + (1ull << (C4_BITS_PER_COL * a))) & colmask;
-    const int mover = (turn == 1) ? 0 : 1;
-    if (mover == 0) b0 |= mv; else b1 |= mv;
-    turn = -turn;
-    const int res = c4_result(b0, b1, mover);
+    if (a < 0 || a >= G::ACTIONS) { done[i] = 0; winner[i] = 0; return; }
+    GameState s;
+    s.bb0 = bb0[i]; s.bb1 = bb1[i]; s.turn = turns[i];
+    s.aux = G::root_aux(s.bb0, s.bb1);
+    G::step(s, a);
+    const int res = G::result(s);
     const bool fin = res >= 0;
     done[i] = fin ? 1 : 0;
     winner[i] = res == 1 ? 1 : (res == 2 ? -1 : 0);
-    if (fin && reset_finished) { b0 = 0; b1 = 0; turn = 1; }
-    bb0[i] = b0; bb1[i] = b1; turns[i] = turn;
+    if (fin && reset_finished) { s.bb0 = 0; s.bb1 = 0; s.turn = 1; }
+    bb0[i] = s.bb0; bb1[i] = s.bb1; turns[i] = s.turn;
 }
 
-inline int groups_grid(int B) { return (B + TREES_PER_WAVE - 1) / TREES_PER_WAVE; }
+__global__ void k_bump_call(uint64_t *ctr) { *ctr += 1; }
+
+inline unsigned grid_for(int B, int trees_per_wg) { return static_cast<unsigned>((B + trees_per_wg - 1) / trees_per_wg); }
 
 }  // namespace
 
 // ------------------------------------------------------------------ launchers
 
-void launch_import(const int8_t *boards, const int32_t *turns, RootState rs, int B, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_import, dim3((B + 255) / 256), dim3(256), 0, s, boards, turns, rs, B);
-}
-
-void launch_set_roots(const uint64_t *bb0, const uint64_t *bb1, const int32_t *turns, RootState rs,
-                      int B, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_set_roots, dim3((B + 255) / 256), dim3(256), 0, s, bb0, bb1, turns, rs, B);
-}
-
-__global__ void k_bump_call(uint64_t *ctr) { *ctr += 1; }
-
-void launch_bump_call(uint64_t *call_ctr, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_bump_call, dim3(1), dim3(1), 0, s, call_ctr);
-}
-
-// Trees per wavefront for the two heavy kernels (AZ_TREES_PER_WAVE, default 8 = all lanes
+// Trees per wavefront for Connect4's two heavy kernels (AZ_TREES_PER_WAVE, default 8 = all lanes
 // busy).  Measured on MI355X at 8192 trees, K=4 (hash evaluator): 8 -> 75.6 us per selection
 // launch, 4 -> 96.4, 2 -> 142.4, 1 -> 236.5: the kernels are bound by instruction issue and
 // dependent-instruction latency, not by memory latency, so spreading the trees over more
 // wavefronts only multiplies the instruction count.
-int trees_per_wave()
+int trees_per_wave(int lanes)
 {
     static const int v = [] {
         const char *e = getenv("AZ_TREES_PER_WAVE");
         int t = e ? atoi(e) : 8;
         return (t == 1 || t == 2 || t == 4 || t == 8) ? t : 8;
     }();
-    return v;
+    const int max_tpw = WAVE / lanes;
+    return v < max_tpw ? v : max_tpw;
 }
 
-void launch_select(TreeArena ar, RootState rs, LeafBuf lf, SearchParams p, int K, bool vl,
+#define AZ_DISPATCH(game, ...)                                                     \
+    do {                                                                           \
+        if ((game) == Connect4Dev::GAME_ID) { using G = Connect4Dev; __VA_ARGS__; } \
+        else { using G = OthelloDev; __VA_ARGS__; }                                 \
+    } while (0)
+
+void launch_import(int game, const int8_t *boards, const int32_t *turns, RootState rs, int B, hipStream_t s)
+{
+    AZ_DISPATCH(game, hipLaunchKernelGGL(k_import<G>, dim3((B + 255) / 256), dim3(256), 0, s, boards, turns, rs, B));
+}
+
+void launch_set_roots(int game, const uint64_t *bb0, const uint64_t *bb1, const int32_t *turns, RootState rs,
+                      int B, hipStream_t s)
+{
+    AZ_DISPATCH(game, hipLaunchKernelGGL(k_set_roots<G>, dim3((B + 255) / 256), dim3(256), 0, s, bb0, bb1, turns, rs, B));
+}
+
+void launch_bump_call(uint64_t *call_ctr, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_bump_call, dim3(1), dim3(1), 0, s, call_ctr);
+}
+
+void launch_select(int game, TreeArena ar, RootState rs, LeafBuf lf, SearchParams p, int K, bool vl,
                    unsigned long long *counters, hipStream_t s)
 {
-    const int tpw = trees_per_wave();
-    const dim3 grid((ar.B + tpw - 1) / tpw), block(WAVE);
-    if (vl) hipLaunchKernelGGL(k_select<true>, grid, block, 0, s, ar, rs, lf, p, K, tpw, counters);
-    else    hipLaunchKernelGGL(k_select<false>, grid, block, 0, s, ar, rs, lf, p, K, tpw, counters);
+    AZ_DISPATCH(game, {
+        const int tpw = trees_per_wave(G::LANES);
+        const dim3 grid(grid_for(ar.B, tpw)), block(WAVE);
+        if (vl) hipLaunchKernelGGL((k_select<G, true>), grid, block, 0, s, ar, rs, lf, p, K, tpw, counters);
+        else    hipLaunchKernelGGL((k_select<G, false>), grid, block, 0, s, ar, rs, lf, p, K, tpw, counters);
+    });
 }
 
-void launch_backprop(TreeArena ar, LeafBuf lf, SearchParams p, int K, bool vl, bool fused,
+void launch_backprop(int game, TreeArena ar, LeafBuf lf, SearchParams p, int K, bool vl, bool fused,
                      EvalIn in, unsigned long long *counters, int *err, hipStream_t s)
 {
-    const int tpw = trees_per_wave();
-    const dim3 grid((ar.B + tpw - 1) / tpw), block(WAVE);
-    if (vl && fused)        hipLaunchKernelGGL((k_backprop<true, true>), grid, block, 0, s, ar, lf, p, K, tpw, in, counters, err);
-    else if (vl && !fused)  hipLaunchKernelGGL((k_backprop<true, false>), grid, block, 0, s, ar, lf, p, K, tpw, in, counters, err);
-    else if (!vl && fused)  hipLaunchKernelGGL((k_backprop<false, true>), grid, block, 0, s, ar, lf, p, K, tpw, in, counters, err);
-    else                    hipLaunchKernelGGL((k_backprop<false, false>), grid, block, 0, s, ar, lf, p, K, tpw, in, counters, err);
+    AZ_DISPATCH(game, {
+        const int tpw = trees_per_wave(G::LANES);
+        const dim3 grid(grid_for(ar.B, tpw)), block(WAVE);
+        if (vl && fused)        hipLaunchKernelGGL((k_backprop<G, true, true>), grid, block, 0, s, ar, lf, p, K, tpw, in, counters, err);
+        else if (vl && !fused)  hipLaunchKernelGGL((k_backprop<G, true, false>), grid, block, 0, s, ar, lf, p, K, tpw, in, counters, err);
+        else if (!vl && fused)  hipLaunchKernelGGL((k_backprop<G, false, true>), grid, block, 0, s, ar, lf, p, K, tpw, in, counters, err);
+        else                    hipLaunchKernelGGL((k_backprop<G, false, false>), grid, block, 0, s, ar, lf, p, K, tpw, in, counters, err);
+    });
 }
 
-void launch_remove_vl(TreeArena ar, LeafBuf lf, SearchParams p, int K, int strideK, hipStream_t s)
+void launch_remove_vl(int game, TreeArena ar, LeafBuf lf, SearchParams p, int K, int strideK, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_remove_vl, dim3(groups_grid(ar.B)), dim3(WAVE), 0, s, ar, lf, p, K, strideK);
+    AZ_DISPATCH(game, hipLaunchKernelGGL(k_remove_vl<G>, dim3(grid_for(ar.B, WAVE / G::LANES)), dim3(WAVE), 0, s, ar,
+                                         lf, p, K, strideK));
 }
 
-void launch_export(LeafBuf lf, SearchParams p, int n_leaves, bool gen_sym, int8_t *boards,
+void launch_export(int game, LeafBuf lf, SearchParams p, int n_leaves, bool gen_sym, int8_t *boards,
                    uint8_t *valid_mask, float *features, hipStream_t s)
 {
-    const int64_t threads = static_cast<int64_t>(n_leaves) * C4_CELLS;
-    hipLaunchKernelGGL(k_export, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0, s,
-                       lf, p, n_leaves, gen_sym ? 1 : 0, boards, valid_mask, features);
+    AZ_DISPATCH(game, {
+        const int64_t threads = static_cast<int64_t>(n_leaves) * G::CELLS;
+        hipLaunchKernelGGL(k_export<G>, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0, s, lf, p,
+                           n_leaves, gen_sym ? 1 : 0, boards, valid_mask, features);
+    });
 }
 
-void launch_prune(TreeArena ar, SearchParams p, const int32_t *actions, int32_t *noise_req,
+void launch_prune(int game, TreeArena ar, SearchParams p, const int32_t *actions, int32_t *noise_req,
                   bool dev_noise, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_prune, dim3(groups_grid(ar.B)), dim3(WAVE), 0, s, ar, p, actions, noise_req,
-                       dev_noise ? 1 : 0);
+    AZ_DISPATCH(game, hipLaunchKernelGGL(k_prune<G>, dim3(grid_for(ar.B, WAVE / G::LANES)), dim3(WAVE), 0, s, ar, p,
+                                         actions, noise_req, dev_noise ? 1 : 0));
 }
 
-void launch_apply_noise(TreeArena ar, const int32_t *noise_req, const float *noise, hipStream_t s)
+void launch_apply_noise(int game, TreeArena ar, const int32_t *noise_req, const float *noise, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_apply_noise, dim3(groups_grid(ar.B)), dim3(WAVE), 0, s, ar, noise_req, noise);
+    AZ_DISPATCH(game, hipLaunchKernelGGL(k_apply_noise<G>, dim3(grid_for(ar.B, WAVE / G::LANES)), dim3(WAVE), 0, s, ar,
+                                         noise_req, noise));
 }
 
 void launch_reset_masked(TreeArena ar, const uint8_t *mask, hipStream_t s)
@@ -932,34 +919,35 @@ void launch_reset_masked(TreeArena ar, const uint8_t *mask, hipStream_t s)
     hipLaunchKernelGGL(k_reset_masked, dim3((ar.B + 255) / 256), dim3(256), 0, s, ar, mask);
 }
 
-void launch_counts(TreeArena ar, int32_t *counts, hipStream_t s)
+void launch_counts(int game, TreeArena ar, int32_t *counts, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_root_query<false>, dim3(groups_grid(ar.B)), dim3(WAVE), 0, s, ar, counts,
-                       static_cast<float *>(nullptr));
+    AZ_DISPATCH(game, hipLaunchKernelGGL((k_root_query<G, false>), dim3(grid_for(ar.B, WAVE / G::LANES)), dim3(WAVE), 0,
+                                         s, ar, counts, static_cast<float *>(nullptr)));
 }
 
-void launch_root_stats(TreeArena ar, float *stats, hipStream_t s)
+void launch_root_stats(int game, TreeArena ar, float *stats, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_root_query<true>, dim3(groups_grid(ar.B)), dim3(WAVE), 0, s, ar,
-                       static_cast<int32_t *>(nullptr), stats);
-}
-
-void launch_rollout(LeafBuf lf, SearchParams p, int B, float *policy, float *d, float *p1w, float *p2w, float *ml,
-                    uint8_t *is_term, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_rollout, dim3((B + 255) / 256), dim3(256), 0, s, lf, p, B, policy, d, p1w, p2w, ml, is_term);
-}
-
-void launch_c4_step(uint64_t *bb0, uint64_t *bb1, int32_t *turns, const int32_t *actions,
-                    uint8_t *done, int32_t *winner, int64_t n, bool reset_finished, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_c4_step, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, bb0, bb1,
-                       turns, actions, done, winner, n, reset_finished ? 1 : 0);
+    AZ_DISPATCH(game, hipLaunchKernelGGL((k_root_query<G, true>), dim3(grid_for(ar.B, WAVE / G::LANES)), dim3(WAVE), 0,
+                                         s, ar, static_cast<int32_t *>(nullptr), stats));
 }
 
 void launch_init_trees(TreeArena ar, hipStream_t s)
 {
     hipLaunchKernelGGL(k_init_trees, dim3((ar.B + 255) / 256), dim3(256), 0, s, ar);
+}
+
+void launch_rollout(int game, LeafBuf lf, SearchParams p, int B, float *policy, float *d, float *p1w, float *p2w,
+                    float *ml, uint8_t *is_term, hipStream_t s)
+{
+    AZ_DISPATCH(game, hipLaunchKernelGGL(k_rollout<G>, dim3((B + 255) / 256), dim3(256), 0, s, lf, p, B, policy, d, p1w,
+                                         p2w, ml, is_term));
+}
+
+void launch_game_step(int game, uint64_t *bb0, uint64_t *bb1, int32_t *turns, const int32_t *actions,
+                      uint8_t *done, int32_t *winner, int64_t n, bool reset_finished, hipStream_t s)
+{
+    AZ_DISPATCH(game, hipLaunchKernelGGL(k_game_step<G>, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s,
+                                         bb0, bb1, turns, actions, done, winner, n, reset_finished ? 1 : 0));
 }
 
 }  // namespace az

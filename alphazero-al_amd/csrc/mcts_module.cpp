@@ -294,4 +294,5 @@ PYBIND11_MODULE(mcts_cpp, m)
         .def_readwrite("vl_count", &az_search_config::vl_count);
 
     register_game<AZ_GAME_CONNECT4>(m, "Connect4");
+    register_game<AZ_GAME_OTHELLO>(m, "Othello");
 }

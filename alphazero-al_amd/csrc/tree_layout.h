@@ -64,6 +64,11 @@ constexpr int C4_ROWS = 6, C4_COLS = 7, C4_CELLS = 42, C4_ACTIONS = 7, C4_BITS_P
 constexpr int C4_MAX_PATH = 44;                    // root + at most 42 plies, padded
 constexpr int C4_STATS = 6 + 8 * C4_ACTIONS;       // get_root_stats row (MCTS.h:634-635)
 
-constexpr int LANES_PER_TREE = 8;                  // one lane per edge (7 used), 8 trees per wave
+// Othello geometry (Othello.h:35-46): 64 squares + pass, up to 33 legal moves, a descent is at
+// most 60 placements plus passes
+constexpr int OT_CELLS = 64, OT_ACTIONS = 65, OT_MAX_PATH = 136;
+constexpr int OT_STATS = 6 + 8 * OT_ACTIONS;
+
+constexpr int LANES_PER_TREE = 8;                  // Connect4: one lane per edge (7 used), 8 trees per wave
 
 }  // namespace az

@@ -34,6 +34,7 @@ extern "C" {
 #define AZ_ERR_STATE     4   /* call sequence not supported                              */
 
 #define AZ_GAME_CONNECT4 0
+#define AZ_GAME_OTHELLO  1
 
 /* Same fields, order and defaults as the reference SearchConfig (MCTSNode.h:47-61),
  * exposed as a LIVE struct exactly like `BatchedMCTS.config` (mcts_bindings.cpp:55-58):

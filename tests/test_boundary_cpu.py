@@ -259,3 +259,19 @@ def test_reference_selfplay_harness_g8(built, monkeypatch):
                 assert np.array_equal(bits(got), bits(ref)), (i, nm)
             else:
                 assert np.array_equal(got, ref), (i, nm)
+
+
+def test_othello_env_against_reference_fixture(built):
+    from src.env_cpp.othello import Env
+    from test_oracle_golden import replay_othello_env
+    g = replay_othello_env(Env)
+    inv = np.array([[Env.inverse_symmetry_action(sid, a) for a in range(65)] for sid in range(8)], np.int32)
+    assert np.array_equal(inv, g["inv_action"])
+    e = Env()
+    assert Env.NUM_SYMMETRIES == 8 and e.board.dtype == np.float32 and e.current_state().shape == (1, 3, 8, 8)
+    c = pickle.loads(pickle.dumps(e))
+    assert c.turn == e.turn and np.array_equal(c.board, e.board)
+    from src import mcts_cpp
+    cls = mcts_cpp.BatchedMCTS_Othello
+    assert (cls.action_size, cls.board_size, tuple(cls.board_shape)) == (65, 64, (8, 8))
+    assert hasattr(mcts_cpp, "RolloutEvaluator_Othello")

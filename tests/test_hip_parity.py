@@ -225,3 +225,45 @@ def test_rollout_search_on_device(mcts_cpp):
     co = S.counts_of(o, 256)
     assert (c.argmax(1) == co.argmax(1)).mean() > 0.6
     assert np.abs(c / 299.0 - co / 299.0).mean() < 0.06
+
+
+# ------------------------------------------------------------------ Othello (a32, BASELINE config 4)
+@pytest.mark.parametrize("name", S.OTHELLO_SCENARIOS)
+def test_othello_scenarios_vs_reference_fixtures(mcts_cpp, name):
+    from test_oracle_golden import check_othello
+    check_othello(name, mcts_cpp.BatchedMCTS_Othello)
+
+
+def test_othello_vs_oracle_side_by_side(mcts_cpp):
+    """Seeded actor configuration (symmetry ids over {0,2,6,7}, Dirichlet noise over up to 33
+    edges, score utility), larger batch than the fixtures."""
+    rng = np.random.default_rng(31)
+    boards, turns = S.ot_openings(rng, 96, 30)
+    res = []
+    for make in (mcts_cpp.BatchedMCTS_Othello, O.BatchedMCTS_Othello):
+        m = make(96)
+        S.apply_cfg(m, dict(S.OT_ACTOR_CFG, c_base=400.0))
+        m.set_seed(17)
+        res.append(S.play_plies(m, boards, turns, 80, 4, 4, record_leaves=True, game=S.OthelloGame))
+    hip, orc = res
+    assert np.array_equal(hip["counts"], orc["counts"])
+    assert np.array_equal(hip["sym"], orc["sym"])
+    assert np.array_equal(hip["leaf_sig"], orc["leaf_sig"])
+    assert np.array_equal(bits(hip["stats"]), bits(orc["stats"]))
+
+
+def test_othello_config4_size_invariants(mcts_cpp):
+    """BASELINE config 4 shape: 4096 trees, n_playout 400, K=4 (one ply)."""
+    B, n, K = 4096, 400, 4
+    boards = np.tile(S.ot_start()[None], (B, 1, 1)); turns = np.ones(B, np.int32)
+    m = mcts_cpp.BatchedMCTS_Othello(B)
+    S.apply_cfg(m, dict(S.OT_DET_CFG, c_base=2000.0))
+    S.playout(m, boards, turns, n, K, game=S.OthelloGame)
+    st = np.array(m.get_all_root_stats()); c = S.counts_of(m, B, 65)
+    assert st.shape == (B, 526) and (st[:, 0] == n).all() and (c.sum(1) == n - 1).all()
+    assert (c == c[0]).all()                       # identical roots, identical trees
+    o = O.BatchedMCTS_Othello(1)
+    S.apply_cfg(o, dict(S.OT_DET_CFG, c_base=2000.0))
+    S.playout(o, boards[:1], turns[:1], n, K, game=S.OthelloGame)
+    assert np.array_equal(c[0], S.counts_of(o, 1, 65)[0])
+    assert np.array_equal(bits(st[0]), bits(o.get_all_root_stats()[0]))
