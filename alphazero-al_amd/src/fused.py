@@ -162,6 +162,11 @@ class FusedSearch:
             probs = log_prob.float().exp()
             wdl = value_lp.exp().float()
             ml = (steps * self.aux_scale).float()
+            if self.w._game_name == "Othello":
+                # the Othello head predicts a disc difference; the search consumes its utility
+                # (Othello/Network.py:247-249)
+                scale = float(getattr(self.net, "score_scale", 8.0))
+                ml = torch.atan(ml / scale) * (2.0 / 3.141592653589793)
         return probs.contiguous(), wdl.contiguous(), ml.reshape(-1).contiguous()
 
     def _iteration(self, K, vl):

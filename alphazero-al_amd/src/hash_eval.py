@@ -62,3 +62,52 @@ class HashEvaluator(torch.nn.Module):
             else torch.as_tensor(np.asarray(action_mask), device=f.device).to(torch.bool)
         p, w, ml = self.predict_device(f, m)
         return p.cpu().numpy(), w.cpu().numpy(), ml.view(-1, 1).cpu().numpy()
+
+
+class OthelloHashEvaluator(torch.nn.Module):
+    """The same idea for Othello (tests/scenarios.py ot_hash_eval): 65 policy values from five
+    re-mixed words, WDL from three 5-bit weights, auxiliary utility = 6 bits / 32 - 1."""
+    is_device_evaluator = True
+    n_actions = 65
+
+    def __init__(self, device="cuda"):
+        super().__init__()
+        self.register_buffer("anchor", torch.zeros(1, device=device))
+
+    @torch.no_grad()
+    def predict_device(self, feats, mask):
+        dev = feats.device
+        n = feats.shape[0]
+        turn = feats[:, 2, 0, 0].to(torch.int64)
+        grid = ((feats[:, 0] - feats[:, 1]) * feats[:, 2]).to(torch.int64).reshape(n, 64)
+        bit = torch.ones((), dtype=torch.int64, device=dev) << torch.arange(64, device=dev)
+        bb0 = (bit * (grid == 1)).sum(1)
+        bb1 = (bit * (grid == -1)).sum(1)
+        x = bb0 * _c(0x9E3779B97F4A7C15)
+        x = x ^ ((bb1 + _c(0x7F4A7C159E3779B9)) * _c(0xBF58476D1CE4E5B9))
+        x = x + torch.where(turn == 1, torch.full_like(x, _c(0x94D049BB133111EB)),
+                            torch.full_like(x, _c(0x2545F4914F6CDD1D)))
+        x = _xorshift(x, 30) * _c(0xBF58476D1CE4E5B9)
+        x = _xorshift(x, 27) * _c(0x94D049BB133111EB)
+        x = _xorshift(x, 31)
+        sh = torch.arange(16, device=dev) * 4
+        words = []
+        for k in range(5):
+            hk = x + _c((0x9E3779B97F4A7C15 * (k + 1)) & ((1 << 64) - 1))
+            hk = _xorshift(hk, 29) * _c(0xBF58476D1CE4E5B9)
+            hk = _xorshift(hk, 32)
+            words.append((1 + ((hk.unsqueeze(1) >> sh) & 15)).to(torch.float32) / 16.0)
+        probs = torch.cat(words, 1)[:, :65] * mask.to(torch.float32)
+        w = torch.stack([1 + ((x >> s) & 31) for s in (28, 33, 38)], 1)
+        wdl = w.to(torch.float32) / w.sum(1, keepdim=True).to(torch.float32)
+        aux = ((x >> 43) & 63).to(torch.float32) / 32.0 - 1.0
+        return probs, wdl, aux
+
+    @torch.no_grad()
+    def predict(self, state, action_mask=None):
+        import numpy as np
+        f = torch.as_tensor(np.asarray(state), dtype=torch.float32, device=self.anchor.device)
+        m = torch.ones((f.shape[0], 65), dtype=torch.bool, device=f.device) if action_mask is None \
+            else torch.as_tensor(np.asarray(action_mask), device=f.device).to(torch.bool)
+        p, w, aux = self.predict_device(f, m)
+        return p.cpu().numpy(), w.cpu().numpy(), aux.view(-1, 1).cpu().numpy()

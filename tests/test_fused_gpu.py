@@ -317,3 +317,30 @@ def test_device_selfplay_driver(env):
     used = env["F"].C.c_int64()
     env["F"].check(env["F"].lib().az_mcts_max_used(sp.h, env["F"].C.byref(used)))
     assert 1 < used.value <= env["F"].lib().az_mcts_capacity(sp.h)
+
+
+def test_fused_path_othello_bit_exact_vs_oracle(env):
+    """Config-4 game through the device-resident loop: 65 actions, passes, score utility."""
+    rng = np.random.default_rng(44)
+    boards, turns = S.ot_openings(rng, 48, 40)
+    cfg = dict(S.OT_DET_CFG, c_base=400.0)
+    n, K, plies = 80, 4, 4
+    o = O.BatchedMCTS_Othello(48)
+    S.apply_cfg(o, cfg)
+    ref = S.play_plies(o, boards, turns, n, K, plies, game=S.OthelloGame)
+    w = env["W"].BatchedMCTS(48, c_init=cfg["c_init"], c_base=cfg["c_base"], alpha=0.0, n_playout=n,
+                             game_name="Othello", noise_epsilon=0.0, fpu_reduction=cfg["fpu_reduction"],
+                             use_symmetry=False, score_utility_factor=cfg["score_utility_factor"],
+                             score_scale=cfg["score_scale"])
+    net = env["H"].OthelloHashEvaluator("cuda")
+    b, t = boards.copy(), turns.copy()
+    for ply in range(plies):
+        w.batch_playout(net, b, t, vl_batch=K)
+        assert w._fused is not None
+        c = w.get_visits_count().astype(np.int32)
+        assert np.array_equal(c, ref["counts"][ply])
+        assert np.array_equal(bits(np.array(w.mcts.get_all_root_stats())), bits(ref["stats"][ply]))
+        acts = np.argmax(c, 1).astype(np.int32)
+        w.prune_roots(acts)
+        for i in range(48):
+            t[i] = S.OthelloGame.advance(b[i], int(t[i]), int(acts[i]))

@@ -223,8 +223,18 @@ def test_rollout_search_on_device(mcts_cpp):
     so = o.get_all_root_stats()
     assert abs(float(st["root_Q"].mean()) - float(so[:, 1].mean())) < 0.03
     co = S.counts_of(o, 256)
-    assert (c.argmax(1) == co.argmax(1)).mean() > 0.6
-    assert np.abs(c / 299.0 - co / 299.0).mean() < 0.06
+    # two independent 300-playout searches of the reference itself agree on the most visited
+    # move in about half of these positions; the visit distributions are close on average
+    o2 = O.BatchedMCTS_Connect4(256)
+    S.apply_cfg(o2, dict(c_init=4.0, c_base=500.0, dirichlet_alpha=0.0, noise_epsilon=0.0, fpu_reduction=0.0,
+                         use_symmetry=False, mlh_slope=0.0, mlh_cap=0.2, value_decay=1.0))
+    o2.set_seed(4)
+    o2.search_rollout(boards, turns, 300)
+    co2 = S.counts_of(o2, 256)
+    ref_agree = (co.argmax(1) == co2.argmax(1)).mean()
+    ref_dist = np.abs(co / 299.0 - co2 / 299.0).mean()
+    assert (c.argmax(1) == co.argmax(1)).mean() > ref_agree - 0.12
+    assert np.abs(c / 299.0 - co / 299.0).mean() < ref_dist * 1.3 + 0.01
 
 
 # ------------------------------------------------------------------ Othello (a32, BASELINE config 4)
