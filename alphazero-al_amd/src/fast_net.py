@@ -43,6 +43,7 @@ def glue():
             L.az_nn_qkv_prep.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i64, f32, vp]
             L.az_nn_attn_post.argtypes = [vp, vp, vp, i64, vp]
             L.az_nn_heads_prep.argtypes = [vp, vp, vp, f32, vp, vp, i64, f32, vp]
+            L.az_nn_conv_block.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, i64, f32, vp]
             _GLUE = L
         except OSError:
             _GLUE = False
@@ -116,6 +117,7 @@ class FastConnect4Net(torch.nn.Module):
         self.hip = (self.device.type == "cuda" and dtype == torch.bfloat16 and self.embed_dim == 32
                     and self.h_dim == 64 and heads == 4 and os.environ.get("AZ_NN_GLUE", "1") != "0"
                     and glue() is not None)
+        self.mfma_conv = self.hip and os.environ.get("AZ_NN_MFMA_CONV", "1") != "0"
 
     @classmethod
     def from_module(cls, net, dtype=torch.bfloat16, device=None):
@@ -164,17 +166,31 @@ class FastConnect4Net(torch.nn.Module):
         L.az_nn_embed(x.data_ptr(), self.emb_own.data_ptr(), self.emb_opp.data_ptr(), self.pos.data_ptr(),
                       t.data_ptr(), bsz, self.embed_dim, s)
         n_el = bsz * CELLS * c_dim
-        conv = self._conv_img(t, self.stem_w).contiguous()
-        t = torch.empty((bsz, CELLS, c_dim), dtype=bf, device=dev)
-        L.az_nn_silu_add(conv.data_ptr(), self.stem_b.data_ptr(), c_dim, None, t.data_ptr(), n_el, s)
-        y = torch.empty_like(t)
-        for w, b, g, beta in self.res:
-            L.az_nn_groupnorm1(t.data_ptr(), getattr(self, g).data_ptr(), getattr(self, beta).data_ptr(),
-                               y.data_ptr(), bsz, c_dim, 1e-5, s)
-            conv = self._conv_img(y, getattr(self, w)).contiguous()
-            t2 = torch.empty_like(t)
-            L.az_nn_silu_add(conv.data_ptr(), getattr(self, b).data_ptr(), c_dim, t.data_ptr(), t2.data_ptr(), n_el, s)
-            t = t2
+        if self.mfma_conv:
+            # each block is one MFMA kernel (nn_conv.hip)
+            t0 = t
+            t = torch.empty((bsz, CELLS, c_dim), dtype=bf, device=dev)
+            L.az_nn_conv_block(t0.data_ptr(), self.embed_dim, self.stem_w.data_ptr(), self.stem_b.data_ptr(), None,
+                               None, 0, t.data_ptr(), bsz, 1e-5, s)
+            for w, b, g, beta in self.res:
+                t2 = torch.empty_like(t)
+                L.az_nn_conv_block(t.data_ptr(), c_dim, getattr(self, w).data_ptr(), getattr(self, b).data_ptr(),
+                                   getattr(self, g).data_ptr(), getattr(self, beta).data_ptr(), 1, t2.data_ptr(),
+                                   bsz, 1e-5, s)
+                t = t2
+            y = torch.empty_like(t)
+        else:
+            conv = self._conv_img(t, self.stem_w).contiguous()
+            t = torch.empty((bsz, CELLS, c_dim), dtype=bf, device=dev)
+            L.az_nn_silu_add(conv.data_ptr(), self.stem_b.data_ptr(), c_dim, None, t.data_ptr(), n_el, s)
+            y = torch.empty_like(t)
+            for w, b, g, beta in self.res:
+                L.az_nn_groupnorm1(t.data_ptr(), getattr(self, g).data_ptr(), getattr(self, beta).data_ptr(),
+                                   y.data_ptr(), bsz, c_dim, 1e-5, s)
+                conv = self._conv_img(y, getattr(self, w)).contiguous()
+                t2 = torch.empty_like(t)
+                L.az_nn_silu_add(conv.data_ptr(), getattr(self, b).data_ptr(), c_dim, t.data_ptr(), t2.data_ptr(), n_el, s)
+                t = t2
         # gated attention
         rows = bsz * CELLS
         L.az_nn_rmsnorm64(t.data_ptr(), self.pre_w.data_ptr(), y.data_ptr(), rows, 1e-5, s)

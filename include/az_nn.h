@@ -30,6 +30,14 @@ int az_nn_groupnorm1(const void *x, const void *gamma, const void *beta, void *y
  * residual may be NULL; n_elements and channels multiples of 8. */
 int az_nn_silu_add(const void *x, const void *bias, int channels, const void *residual, void *y,
                    int64_t n_elements, void *stream);
+/* One whole convolution block as a single MFMA kernel (nn_conv.hip):
+ *   y = [x +] silu(conv3x3([GroupNorm1(x) * gamma + beta]) + bias)        (Network.py:27-48,166-170)
+ * x (batch, 42, c_in), y (batch, 42, 64); weight_ohwi = the (64, c_in, 3, 3) weight stored
+ * output-major with the input channel fastest, i.e. (64, 3, 3, c_in) contiguous
+ * (torch channels_last memory of the OIHW tensor).  gamma/beta NULL = no normalisation.
+ * Supported: c_in 64 with normalisation (residual 0/1), c_in 32 without either (the stem). */
+int az_nn_conv_block(const void *x, int c_in, const void *weight_ohwi, const void *bias, const void *gamma,
+                     const void *beta, int residual, void *y, int64_t batch, float eps, void *stream);
 /* nn.RMSNorm over the last dimension of 64 */
 int az_nn_rmsnorm64(const void *x, const void *w, void *y, int64_t rows, float eps, void *stream);
 /* qkvg (batch*42, row_len) with row_len 196 or 200 (3*64 q|k|v, 4 gate logits, optional zero

@@ -220,6 +220,42 @@ def test_glue_kernels_match_torch(env):
     torch.cuda.synchronize()
 
 
+def test_mfma_conv_block_matches_torch(env):
+    """nn_conv.hip (implicit-GEMM 3x3 convolution on MFMA with fused GroupNorm / bias / SiLU /
+    residual) against the same block in torch, fp32 maths on the same bf16 inputs."""
+    torch = env["torch"]
+    import ctypes as C
+    import torch.nn.functional as TF
+    from src.fast_net import glue
+    L = glue()
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    bf = torch.bfloat16
+    for B in (8, 37, 1024):                       # full tiles, a ragged tail, many tiles per workgroup
+        for cin, norm, resid in ((64, True, True), (64, True, False), (32, False, False)):
+            x = (torch.randn(B, 42, cin, device="cuda", generator=g) * 1.5 + 0.3).to(bf)
+            w = (torch.randn(64, cin, 3, 3, device="cuda", generator=g) / (3.0 * cin ** 0.5)).to(bf)
+            w_ohwi = w.contiguous(memory_format=torch.channels_last)
+            bias = torch.randn(64, device="cuda", generator=g).to(bf)
+            ga = (1 + 0.2 * torch.randn(cin, device="cuda", generator=g)).to(bf)
+            be = (0.2 * torch.randn(cin, device="cuda", generator=g)).to(bf)
+            y = torch.full((B, 42, 64), float("nan"), device="cuda").to(bf)
+            rc = L.az_nn_conv_block(x.data_ptr(), cin, w_ohwi.data_ptr(), bias.data_ptr(),
+                                    ga.data_ptr() if norm else None, be.data_ptr() if norm else None,
+                                    1 if resid else 0, y.data_ptr(), B, 1e-5, s)
+            assert rc == 0
+            img = x.float().view(B, 6, 7, cin).permute(0, 3, 1, 2)
+            h = TF.group_norm(img, 1, ga.float(), be.float(), 1e-5).to(bf).float() if norm else img
+            ref = TF.silu(TF.conv2d(h, w.float(), bias.float(), padding=1))
+            if resid:
+                ref = ref + img
+            ref = ref.permute(0, 2, 3, 1).reshape(B, 42, 64)
+            torch.cuda.synchronize()
+            err = (y.float() - ref).abs()
+            assert torch.isfinite(y.float()).all()
+            assert err.max().item() < 6e-2 and err.mean().item() < 4e-3, (B, cin, err.max().item(), err.mean().item())
+
+
 def test_fast_net_hip_path_equals_torch_path(env):
     torch = env["torch"]
     from src.fast_net import FastConnect4Net
