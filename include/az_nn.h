@@ -38,6 +38,8 @@ int az_nn_silu_add(const void *x, const void *bias, int channels, const void *re
  * Supported: c_in 64 with normalisation (residual 0/1), c_in 32 without either (the stem). */
 int az_nn_conv_block(const void *x, int c_in, const void *weight_ohwi, const void *bias, const void *gamma,
                      const void *beta, int residual, void *y, int64_t batch, float eps, void *stream);
+/* timing experiments: bit 0 skips the MFMA loop of az_nn_conv_block, bit 1 its store phase */
+int az_nn_debug(int flags);
 /* nn.RMSNorm over the last dimension of 64 */
 int az_nn_rmsnorm64(const void *x, const void *w, void *y, int64_t rows, float eps, void *stream);
 /* qkvg (batch*42, row_len) with row_len 196 or 200 (3*64 q|k|v, 4 gate logits, optional zero
