@@ -1,0 +1,281 @@
+// nn_attn.hip - the evaluator's gated attention block as ONE MFMA kernel, no LDS.
+//
+//   y = x + o_proj( sigmoid(gate) * softmax(q_norm(Q) k_norm(K)^T / sqrt(16)) V )
+//   with [Q | K | V | gate] = qkvg_proj(RMSNorm(x))                     (Network.py:51-93)
+//
+// One wavefront owns one sample (42 tokens padded to 3 row tiles of 16) and keeps every
+// intermediate in registers.  The point of the design is the ORIENTATION of each product:
+// with C/D in the MFMA layout (column = lane & 15, rows = 4*(lane>>4)+reg) a result can feed
+// the next MFMA with no lane movement if that product sums over its ROW index.  So
+//
+//   Q^T, K^T, gate^T = W . H^T      (features x tokens; A = weights, B = H^T)   v_mfma 16x16x32
+//   V               = H . Wv^T      (tokens x features; A = H, B = Wv^T)        v_mfma 16x16x32
+//   S^T             = K . Q^T       (keys x queries;  A = K^T regs, B = Q^T regs) 16x16x16
+//   O^T             = V^T . P^T     (d x queries;     A = V regs,   B = P^T regs) 16x16x16
+//   out^T           = Wo_h . O_h^T  summed over heads (A = weights, B = O^T regs) 16x16x16
+//
+// The per-(token, head) RMSNorm of q and k and the softmax over keys reduce over rows, i.e.
+// over the 4 registers of a lane and the 4 lane groups that share a column: two xor-shuffles.
+// H fragments serve both as B operand (H^T) and as A operand (H): the element sets coincide.
+// All weights (25 KB + 8 KB) live in registers for the whole kernel.  HBM traffic: read x,
+// write y.  Replaces RMSNorm + 196-wide GEMM + split/normalise + SDPA + gate + out-projection
+// (six kernels, 1.8 ms per 32768-leaf iteration in the first profile).
+#include <hip/hip_bf16.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "az_nn.h"
+
+namespace {
+
+constexpr int CELLS = 42, C = 64, HEADS = 4, HD = 16, TT = 3;     // 3 token tiles of 16
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct alignas(16) V8 { uint32_t w[4]; };
+struct alignas(8) V4 { uint32_t w[2]; };
+
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ uint16_t to_bf16(float a)
+{
+    const __hip_bfloat16 x = __float2bfloat16(a);
+    return *reinterpret_cast<const uint16_t *>(&x);
+}
+__device__ __forceinline__ uint32_t pack2(float a, float b)
+{
+    return static_cast<uint32_t>(to_bf16(a)) | (static_cast<uint32_t>(to_bf16(b)) << 16);
+}
+__device__ __forceinline__ s16x4 to_s16x4(const f32x4 &v)
+{
+    union { uint32_t u[2]; s16x4 s; } r;
+    r.u[0] = pack2(v[0], v[1]);
+    r.u[1] = pack2(v[2], v[3]);
+    return r.s;
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(const V8 &v)
+{
+    union { V8 a; bf16x8 b; } r;
+    r.a = v;
+    return r.b;
+}
+__device__ __forceinline__ float bf1(const uint16_t *p) { return __uint_as_float(static_cast<uint32_t>(*p) << 16); }
+__device__ __forceinline__ float col_sum(float v)   // sum over the 4 lane groups that share lane & 15
+{
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ float col_max(float v)
+{
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k((a), (b), (c), 0, 0, 0)
+
+// qkvg: (196, 64) row-major [out][in]: rows 0-63 Q, 64-127 K, 128-191 V, 192-195 gate
+__global__ void __launch_bounds__(256) k_attn_block(const uint16_t *x, const uint16_t *pre_w, const uint16_t *qkvg,
+                                                    const uint16_t *qn_w, const uint16_t *kn_w, const uint16_t *o_w,
+                                                    uint16_t *y, int64_t B, float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+
+    // ---- weights as operand fragments, resident for the whole kernel
+    bf16x8 wq[HEADS][2], wk[HEADS][2], wv[HEADS][2], wg[2];
+#pragma unroll
+    for (int h = 0; h < HEADS; ++h)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int k = 32 * s + 8 * l4;
+            wq[h][s] = *reinterpret_cast<const bf16x8 *>(qkvg + (h * HD + l15) * C + k);
+            wk[h][s] = *reinterpret_cast<const bf16x8 *>(qkvg + (C + h * HD + l15) * C + k);
+            wv[h][s] = *reinterpret_cast<const bf16x8 *>(qkvg + (2 * C + h * HD + l15) * C + k);
+        }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        V8 z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0;
+        if (l15 < HEADS) z = *reinterpret_cast<const V8 *>(qkvg + (3 * C + l15) * C + 32 * s + 8 * l4);
+        wg[s] = as_bf16x8(z);
+    }
+    s16x4 wo[4][HEADS];                       // A[row = out feature][k = 4 inputs of head h]
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+        for (int h = 0; h < HEADS; ++h)
+            wo[ot][h] = *reinterpret_cast<const s16x4 *>(o_w + (ot * 16 + l15) * C + h * HD + 4 * l4);
+    float pw[2][8];                           // prenorm weight of this lane's 16 input channels
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pw[s][j] = bf1(pre_w + 32 * s + 8 * l4 + j);
+    float qnw[4], knw[4];                     // per-head norm weights of this lane's rows d = 4*l4 + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { qnw[r] = bf1(qn_w + 4 * l4 + r); knw[r] = bf1(kn_w + 4 * l4 + r); }
+
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * 4;
+    for (int64_t b = static_cast<int64_t>(blockIdx.x) * 4 + wave; b < B; b += stride) {
+        const uint16_t *xs = x + b * (CELLS * C);
+
+        // ---- H = RMSNorm(x) * w, as MFMA fragments (token = tile*16 + lane&15, 8 channels per k-step)
+        bf16x8 hf[TT][2];
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+            const int tok = tt * 16 + l15;
+            float f[2][8];
+            float ss = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                V8 v; v.w[0] = v.w[1] = v.w[2] = v.w[3] = 0;
+                if (tok < CELLS) v = *reinterpret_cast<const V8 *>(xs + tok * C + 32 * s + 8 * l4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { f[s][2 * i] = bf_lo(v.w[i]); f[s][2 * i + 1] = bf_hi(v.w[i]); }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ss += f[s][j] * f[s][j];
+            }
+            ss = col_sum(ss);
+            const float r = rsqrtf(ss * (1.0f / C) + eps);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                V8 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    o.w[i] = pack2(f[s][2 * i] * r * pw[s][2 * i], f[s][2 * i + 1] * r * pw[s][2 * i + 1]);
+                hf[tt][s] = as_bf16x8(o);
+            }
+        }
+
+        // ---- projections
+        s16x4 qb[HEADS][TT], kb[HEADS][TT], vb[HEADS][TT];
+        float gate[TT][HEADS];
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+#pragma unroll
+            for (int h = 0; h < HEADS; ++h) {
+                f32x4 q = MFMA32(wq[h][0], hf[tt][0], zero);
+                q = MFMA32(wq[h][1], hf[tt][1], q);
+                f32x4 k = MFMA32(wk[h][0], hf[tt][0], zero);
+                k = MFMA32(wk[h][1], hf[tt][1], k);
+                f32x4 v = MFMA32(hf[tt][0], wv[h][0], zero);
+                v = MFMA32(hf[tt][1], wv[h][1], v);
+                // per-(token, head) RMSNorm over d: rows of the column this lane sits in
+                float qs = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+                float ks = k[0] * k[0] + k[1] * k[1] + k[2] * k[2] + k[3] * k[3];
+                qs = col_sum(qs); ks = col_sum(ks);
+                const float qr = rsqrtf(qs * (1.0f / HD) + eps), kr = rsqrtf(ks * (1.0f / HD) + eps);
+                // the reference rounds the projection to bf16 before the norm (bf16 GEMM output)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { q[r] = q[r] * qr * qnw[r]; k[r] = k[r] * kr * knw[r]; }
+                qb[h][tt] = to_s16x4(q);
+                kb[h][tt] = to_s16x4(k);
+                vb[h][tt] = to_s16x4(v);
+            }
+            f32x4 g = MFMA32(wg[0], hf[tt][0], zero);
+            g = MFMA32(wg[1], hf[tt][1], g);
+            // gate logits of token lane&15 sit in rows 0..3 = registers of lane group 0
+#pragma unroll
+            for (int h = 0; h < HEADS; ++h) {
+                const float gl = __shfl(g[h], l15, 64);
+                gate[tt][h] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * gl));
+            }
+        }
+
+        // ---- attention per head, output projection accumulated over heads
+        f32x4 out[4][TT];
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+            for (int qt = 0; qt < TT; ++qt) out[ot][qt] = zero;
+
+#pragma unroll
+        for (int h = 0; h < HEADS; ++h) {
+#pragma unroll
+            for (int qt = 0; qt < TT; ++qt) {
+                // S^T tile rows = keys, column = query lane&15
+                f32x4 st[TT];
+                float m = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < TT; ++kt) {
+                    st[kt] = MFMA16(kb[h][kt], qb[h][qt], zero);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kt * 16 + 4 * l4 + r;
+                        st[kt][r] = key < CELLS ? st[kt][r] * 0.25f : -INFINITY;       // 1/sqrt(16)
+                        m = fmaxf(m, st[kt][r]);
+                    }
+                }
+                m = col_max(m);
+                float den = 0.0f;
+#pragma unroll
+                for (int kt = 0; kt < TT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        st[kt][r] = __builtin_amdgcn_exp2f((st[kt][r] - m) * 1.44269504f);
+                        den += st[kt][r];
+                    }
+                den = col_sum(den);
+                const float inv = __builtin_amdgcn_rcpf(den);
+                f32x4 o = zero;                                  // O^T rows = d, column = query
+#pragma unroll
+                for (int kt = 0; kt < TT; ++kt) {
+                    f32x4 p = st[kt];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p[r] *= inv;
+                    o = MFMA16(vb[h][kt], to_s16x4(p), o);
+                }
+                const float g = gate[qt][h];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] *= g;
+                const s16x4 ob = to_s16x4(o);
+#pragma unroll
+                for (int ot = 0; ot < 4; ++ot) out[ot][qt] = MFMA16(wo[ot][h], ob, out[ot][qt]);
+            }
+        }
+
+        // ---- y = out + x : lane holds 4 consecutive output channels of token qt*16 + lane&15
+        uint16_t *ys = y + b * (CELLS * C);
+#pragma unroll
+        for (int qt = 0; qt < TT; ++qt) {
+            const int tok = qt * 16 + l15;
+            if (tok < CELLS) {
+#pragma unroll
+                for (int ot = 0; ot < 4; ++ot) {
+                    const int ch = ot * 16 + 4 * l4;
+                    const V4 xr = *reinterpret_cast<const V4 *>(xs + tok * C + ch);
+                    V4 o;
+                    o.w[0] = pack2(out[ot][qt][0] + bf_lo(xr.w[0]), out[ot][qt][1] + bf_hi(xr.w[0]));
+                    o.w[1] = pack2(out[ot][qt][2] + bf_lo(xr.w[1]), out[ot][qt][3] + bf_hi(xr.w[1]));
+                    *reinterpret_cast<V4 *>(ys + tok * C + ch) = o;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int az_nn_attn_block(const void *x, const void *prenorm_w, const void *qkvg_w, const void *q_norm_w,
+                     const void *k_norm_w, const void *o_w, void *y, int64_t batch, float eps, void *stream)
+{
+    if (batch <= 0) return 1;
+    const int64_t wgs = (batch + 3) / 4;
+    const unsigned grid = static_cast<unsigned>(wgs < 1024 ? wgs : 1024);
+    hipLaunchKernelGGL(k_attn_block, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint16_t *>(x), static_cast<const uint16_t *>(prenorm_w),
+                       static_cast<const uint16_t *>(qkvg_w), static_cast<const uint16_t *>(q_norm_w),
+                       static_cast<const uint16_t *>(k_norm_w), static_cast<const uint16_t *>(o_w),
+                       static_cast<uint16_t *>(y), batch, eps);
+    return 0;
+}
+
+}  // extern "C"

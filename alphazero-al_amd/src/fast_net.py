@@ -44,6 +44,7 @@ def glue():
             L.az_nn_attn_post.argtypes = [vp, vp, vp, i64, vp]
             L.az_nn_heads_prep.argtypes = [vp, vp, vp, f32, vp, vp, i64, f32, vp]
             L.az_nn_conv_block.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, i64, f32, vp]
+            L.az_nn_attn_block.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, f32, vp]
             _GLUE = L
         except OSError:
             _GLUE = False
@@ -118,6 +119,7 @@ class FastConnect4Net(torch.nn.Module):
                     and self.h_dim == 64 and heads == 4 and os.environ.get("AZ_NN_GLUE", "1") != "0"
                     and glue() is not None)
         self.mfma_conv = self.hip and os.environ.get("AZ_NN_MFMA_CONV", "1") != "0"
+        self.mfma_attn = self.hip and os.environ.get("AZ_NN_MFMA_ATTN", "1") != "0"
 
     @classmethod
     def from_module(cls, net, dtype=torch.bfloat16, device=None):
@@ -193,6 +195,11 @@ class FastConnect4Net(torch.nn.Module):
                 t = t2
         # gated attention
         rows = bsz * CELLS
+        if self.mfma_attn:
+            t2 = torch.empty_like(t)
+            L.az_nn_attn_block(t.data_ptr(), self.pre_w.data_ptr(), self.qkvg_w.data_ptr(), self.qn_w.data_ptr(),
+                               self.kn_w.data_ptr(), self.o_w.data_ptr(), t2.data_ptr(), bsz, 1e-5, s)
+            return self._heads_hip(t2, action_mask, bsz, L, s)
         L.az_nn_rmsnorm64(t.data_ptr(), self.pre_w.data_ptr(), y.data_ptr(), rows, 1e-5, s)
         qkvg = F.linear(y.view(rows, c_dim), self.qkvg_w_pad)                 # (T, 200)
         q = torch.empty((bsz, self.heads, CELLS, c_dim // self.heads), dtype=bf, device=dev)
@@ -204,6 +211,11 @@ class FastConnect4Net(torch.nn.Module):
         a = F.scaled_dot_product_attention(q, k, v).contiguous()
         L.az_nn_attn_post(a.data_ptr(), gate.data_ptr(), y.data_ptr(), bsz, s)
         t = torch.addmm(t.view(rows, c_dim), y.view(rows, c_dim), self.o_w.t()).view(bsz, CELLS, c_dim)
+        return self._heads_hip(t, action_mask, bsz, L, s)
+
+    @torch.no_grad()
+    def _heads_hip(self, t, action_mask, bsz, L, s):
+        dev, bf, c_dim = self.device, torch.bfloat16, self.h_dim
         # heads
         col = torch.empty((bsz, COLS, c_dim), dtype=bf, device=dev)
         mean = torch.empty((bsz, c_dim), dtype=bf, device=dev)

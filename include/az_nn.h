@@ -38,6 +38,12 @@ int az_nn_silu_add(const void *x, const void *bias, int channels, const void *re
  * Supported: c_in 64 with normalisation (residual 0/1), c_in 32 without either (the stem). */
 int az_nn_conv_block(const void *x, int c_in, const void *weight_ohwi, const void *bias, const void *gamma,
                      const void *beta, int residual, void *y, int64_t batch, float eps, void *stream);
+/* The whole gated attention block as a single MFMA kernel (nn_attn.hip):
+ *   y = x + o_proj(sigmoid(gate) * softmax(qnorm(Q) knorm(K)^T / 4) V),  [Q|K|V|gate] = qkvg(RMSNorm(x))
+ * (Network.py:51-93).  x, y (batch, 42, 64); qkvg_w (196, 64) row-major [out][in] with rows
+ * 0-63 Q, 64-127 K, 128-191 V, 192-195 gate; o_w (64, 64) [out][in]; 4 heads of 16. */
+int az_nn_attn_block(const void *x, const void *prenorm_w, const void *qkvg_w, const void *q_norm_w,
+                     const void *k_norm_w, const void *o_w, void *y, int64_t batch, float eps, void *stream);
 /* timing experiments: bit 0 skips the MFMA loop of az_nn_conv_block, bit 1 its store phase */
 int az_nn_debug(int flags);
 /* nn.RMSNorm over the last dimension of 64 */

@@ -256,6 +256,41 @@ def test_mfma_conv_block_matches_torch(env):
             assert err.max().item() < 6e-2 and err.mean().item() < 4e-3, (B, cin, err.max().item(), err.mean().item())
 
 
+def test_mfma_attention_block_matches_torch(env):
+    """nn_attn.hip (RMSNorm -> QKV+gate projection -> per-head RMSNorm -> softmax attention ->
+    gate -> output projection + residual, all on MFMA in registers) against torch fp32."""
+    torch = env["torch"]
+    import ctypes as C
+    import torch.nn.functional as TF
+    from src.fast_net import glue
+    L = glue()
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device="cuda"); g.manual_seed(2)
+    bf = torch.bfloat16
+    rnd = lambda *sh: torch.randn(*sh, device="cuda", generator=g)     # noqa: E731
+    pre = (1 + 0.1 * rnd(64)).to(bf); qn = (1 + 0.1 * rnd(16)).to(bf); kn = (1 + 0.1 * rnd(16)).to(bf)
+    wqkvg = (rnd(196, 64) / 8).to(bf); wo = (rnd(64, 64) / 8).to(bf)
+    for B in (1, 5, 4096):
+        x = (rnd(B, 42, 64) * 1.2).to(bf)
+        y = torch.full_like(x, float("nan"))
+        assert L.az_nn_attn_block(x.data_ptr(), pre.data_ptr(), wqkvg.data_ptr(), qn.data_ptr(), kn.data_ptr(),
+                                  wo.data_ptr(), y.data_ptr(), B, 1e-5, s) == 0
+        xf = x.float()
+        h = TF.rms_norm(xf, (64,), pre.float(), 1e-5).to(bf).float()
+        proj = h @ wqkvg.float().t()
+        q, k, v = proj[..., :192].view(B, 42, 3, 4, 16).unbind(2)
+        gate = torch.sigmoid(proj[..., 192:])
+        q = TF.rms_norm(q, (16,), qn.float(), 1e-5).transpose(1, 2)
+        k = TF.rms_norm(k, (16,), kn.float(), 1e-5).transpose(1, 2)
+        a = TF.scaled_dot_product_attention(q, k, v.transpose(1, 2))
+        a = a * gate.transpose(1, 2).unsqueeze(-1)
+        ref = a.transpose(1, 2).reshape(B, 42, 64) @ wo.float().t() + xf
+        torch.cuda.synchronize()
+        err = (y.float() - ref).abs()
+        assert torch.isfinite(y.float()).all()
+        assert err.max().item() < 8e-2 and err.mean().item() < 6e-3, (B, err.max().item(), err.mean().item())
+
+
 def test_fast_net_hip_path_equals_torch_path(env):
     torch = env["torch"]
     from src.fast_net import FastConnect4Net
