@@ -17,7 +17,7 @@
 // The per-(token, head) RMSNorm of q and k and the softmax over keys reduce over rows, i.e.
 // over the 4 registers of a lane and the 4 lane groups that share a column: two xor-shuffles.
 // H fragments serve both as B operand (H^T) and as A operand (H): the element sets coincide.
-// All weights (25 KB + 8 KB) live in registers for the whole kernel.  HBM traffic: read x,
+// The weights (25 KB + 8 KB) sit in LDS in operand-fragment order.  HBM traffic: read x,
 // write y.  Replaces RMSNorm + 196-wide GEMM + split/normalise + SDPA + gate + out-projection
 // (six kernels, 1.8 ms per 32768-leaf iteration in the first profile).
 #include <hip/hip_bf16.h>
@@ -80,7 +80,7 @@ __device__ __forceinline__ float col_max(float v)
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k((a), (b), (c), 0, 0, 0)
 
 // qkvg: (196, 64) row-major [out][in]: rows 0-63 Q, 64-127 K, 128-191 V, 192-195 gate
-__global__ void __launch_bounds__(256) k_attn_block(const uint16_t *x, const uint16_t *pre_w, const uint16_t *qkvg,
+__global__ void __launch_bounds__(256, 2) k_attn_block(const uint16_t *x, const uint16_t *pre_w, const uint16_t *qkvg,
                                                     const uint16_t *qn_w, const uint16_t *kn_w, const uint16_t *o_w,
                                                     uint16_t *y, int64_t B, float eps)
 {
@@ -88,29 +88,36 @@ __global__ void __launch_bounds__(256) k_attn_block(const uint16_t *x, const uin
     const int wave = threadIdx.x >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
 
-    // ---- weights as operand fragments, resident for the whole kernel
-    bf16x8 wq[HEADS][2], wk[HEADS][2], wv[HEADS][2], wg[2];
-#pragma unroll
-    for (int h = 0; h < HEADS; ++h)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int k = 32 * s + 8 * l4;
-            wq[h][s] = *reinterpret_cast<const bf16x8 *>(qkvg + (h * HD + l15) * C + k);
-            wk[h][s] = *reinterpret_cast<const bf16x8 *>(qkvg + (C + h * HD + l15) * C + k);
-            wv[h][s] = *reinterpret_cast<const bf16x8 *>(qkvg + (2 * C + h * HD + l15) * C + k);
+    // ---- weights: staged once per workgroup into LDS in exactly the order the lanes read them
+    // (fragment f, lane l -> 16 or 8 contiguous bytes at f*64+l), so every operand fetch is one
+    // conflict-free ds_read.  Keeping them out of the register file is what lets two
+    // wavefronts share a SIMD (the kernel is bound by dependent VALU/MFMA latency, not by LDS).
+    __shared__ V8 s_w32[(3 * HEADS * 2 + 2) * 64];          // wq, wk, wv [h][s], wg [s]
+    __shared__ V4 s_w16[4 * HEADS * 64];                    // wo [ot][h]
+    for (int i = threadIdx.x; i < (3 * HEADS * 2 + 2) * 64; i += blockDim.x) {
+        const int f = i >> 6, l = i & 63, ll15 = l & 15, ll4 = l >> 4;
+        V8 v; v.w[0] = v.w[1] = v.w[2] = v.w[3] = 0;
+        if (f < 3 * HEADS * 2) {
+            const int part = f / (HEADS * 2), h = (f >> 1) % HEADS, sk = f & 1;
+            v = *reinterpret_cast<const V8 *>(qkvg + (part * C + h * HD + ll15) * C + 32 * sk + 8 * ll4);
+        } else if (ll15 < HEADS) {
+            v = *reinterpret_cast<const V8 *>(qkvg + (3 * C + ll15) * C + 32 * (f & 1) + 8 * ll4);
         }
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        V8 z; z.w[0] = z.w[1] = z.w[2] = z.w[3] = 0;
-        if (l15 < HEADS) z = *reinterpret_cast<const V8 *>(qkvg + (3 * C + l15) * C + 32 * s + 8 * l4);
-        wg[s] = as_bf16x8(z);
+        s_w32[i] = v;
     }
-    s16x4 wo[4][HEADS];                       // A[row = out feature][k = 4 inputs of head h]
-#pragma unroll
-    for (int ot = 0; ot < 4; ++ot)
-#pragma unroll
-        for (int h = 0; h < HEADS; ++h)
-            wo[ot][h] = *reinterpret_cast<const s16x4 *>(o_w + (ot * 16 + l15) * C + h * HD + 4 * l4);
+    for (int i = threadIdx.x; i < 4 * HEADS * 64; i += blockDim.x) {
+        const int f = i >> 6, l = i & 63, ot = f / HEADS, h = f % HEADS;
+        s_w16[i] = *reinterpret_cast<const V4 *>(o_w + (ot * 16 + (l & 15)) * C + h * HD + 4 * (l >> 4));
+    }
+    __syncthreads();
+    // (the head loop below is not unrolled and indexes these by the runtime head number, so the
+    // reads stay ds_read_b128 / ds_read_b64 inside the loop instead of becoming live registers)
+    auto frag32 = [&](int f) { return as_bf16x8(s_w32[f * 64 + lane]); };     // part*8 + h*2 + s ; gate: 24 + s
+    auto frag16 = [&](int f) {
+        union { V4 v; s16x4 s; } r;
+        r.v = s_w16[f * 64 + lane];
+        return r.s;
+    };
     float pw[2][8];                           // prenorm weight of this lane's 16 input channels
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -152,35 +159,13 @@ __global__ void __launch_bounds__(256) k_attn_block(const uint16_t *x, const uin
             }
         }
 
-        // ---- projections
-        s16x4 qb[HEADS][TT], kb[HEADS][TT], vb[HEADS][TT];
+        // ---- gate logits of every token (rows 0..3 of the gate tile = registers of lane group 0)
         float gate[TT][HEADS];
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt) {
-#pragma unroll
-            for (int h = 0; h < HEADS; ++h) {
-                f32x4 q = MFMA32(wq[h][0], hf[tt][0], zero);
-                q = MFMA32(wq[h][1], hf[tt][1], q);
-                f32x4 k = MFMA32(wk[h][0], hf[tt][0], zero);
-                k = MFMA32(wk[h][1], hf[tt][1], k);
-                f32x4 v = MFMA32(hf[tt][0], wv[h][0], zero);
-                v = MFMA32(hf[tt][1], wv[h][1], v);
-                // per-(token, head) RMSNorm over d: rows of the column this lane sits in
-                float qs = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
-                float ks = k[0] * k[0] + k[1] * k[1] + k[2] * k[2] + k[3] * k[3];
-                qs = col_sum(qs); ks = col_sum(ks);
-                const float qr = rsqrtf(qs * (1.0f / HD) + eps), kr = rsqrtf(ks * (1.0f / HD) + eps);
-                // the reference rounds the projection to bf16 before the norm (bf16 GEMM output)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { q[r] = q[r] * qr * qnw[r]; k[r] = k[r] * kr * knw[r]; }
-                qb[h][tt] = to_s16x4(q);
-                kb[h][tt] = to_s16x4(k);
-                vb[h][tt] = to_s16x4(v);
-            }
-            f32x4 g = MFMA32(wg[0], hf[tt][0], zero);
-            g = MFMA32(wg[1], hf[tt][1], g);
-            // gate logits of token lane&15 sit in rows 0..3 = registers of lane group 0
+            f32x4 g = MFMA32(frag32(24), hf[tt][0], zero);
+            g = MFMA32(frag32(25), hf[tt][1], g);
 #pragma unroll
             for (int h = 0; h < HEADS; ++h) {
                 const float gl = __shfl(g[h], l15, 64);
@@ -188,15 +173,36 @@ __global__ void __launch_bounds__(256) k_attn_block(const uint16_t *x, const uin
             }
         }
 
-        // ---- attention per head, output projection accumulated over heads
         f32x4 out[4][TT];
 #pragma unroll
         for (int ot = 0; ot < 4; ++ot)
 #pragma unroll
             for (int qt = 0; qt < TT; ++qt) out[ot][qt] = zero;
 
-#pragma unroll
+        // ---- one head at a time: projection, attention, contribution to the output projection.
+        // Not unrolled: the four heads share the code and, more importantly, the registers.
+#pragma unroll 1
         for (int h = 0; h < HEADS; ++h) {
+            s16x4 qb[TT], kb[TT], vb[TT];
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) {
+                f32x4 q = MFMA32(frag32(h * 2), hf[tt][0], zero);
+                q = MFMA32(frag32(h * 2 + 1), hf[tt][1], q);
+                f32x4 k = MFMA32(frag32(8 + h * 2), hf[tt][0], zero);
+                k = MFMA32(frag32(8 + h * 2 + 1), hf[tt][1], k);
+                f32x4 v = MFMA32(hf[tt][0], frag32(16 + h * 2), zero);
+                v = MFMA32(hf[tt][1], frag32(16 + h * 2 + 1), v);
+                // per-(token, head) RMSNorm over d: rows of the column this lane sits in
+                float qs = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+                float ks = k[0] * k[0] + k[1] * k[1] + k[2] * k[2] + k[3] * k[3];
+                qs = col_sum(qs); ks = col_sum(ks);
+                const float qr = rsqrtf(qs * (1.0f / HD) + eps), kr = rsqrtf(ks * (1.0f / HD) + eps);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { q[r] = q[r] * qr * qnw[r]; k[r] = k[r] * kr * knw[r]; }
+                qb[tt] = to_s16x4(q);
+                kb[tt] = to_s16x4(k);
+                vb[tt] = to_s16x4(v);
+            }
 #pragma unroll
             for (int qt = 0; qt < TT; ++qt) {
                 // S^T tile rows = keys, column = query lane&15
@@ -204,7 +210,7 @@ __global__ void __launch_bounds__(256) k_attn_block(const uint16_t *x, const uin
                 float m = -INFINITY;
 #pragma unroll
                 for (int kt = 0; kt < TT; ++kt) {
-                    st[kt] = MFMA16(kb[h][kt], qb[h][qt], zero);
+                    st[kt] = MFMA16(kb[kt], qb[qt], zero);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int key = kt * 16 + 4 * l4 + r;
@@ -222,21 +228,17 @@ __global__ void __launch_bounds__(256) k_attn_block(const uint16_t *x, const uin
                         den += st[kt][r];
                     }
                 den = col_sum(den);
-                const float inv = __builtin_amdgcn_rcpf(den);
+                // normalise after the product: O^T = (V^T . E^T) / den, one scale per output element
+                const float gq = h == 0 ? gate[qt][0] : (h == 1 ? gate[qt][1] : (h == 2 ? gate[qt][2] : gate[qt][3]));
+                const float scale = __builtin_amdgcn_rcpf(den) * gq;
                 f32x4 o = zero;                                  // O^T rows = d, column = query
 #pragma unroll
-                for (int kt = 0; kt < TT; ++kt) {
-                    f32x4 p = st[kt];
+                for (int kt = 0; kt < TT; ++kt) o = MFMA16(vb[kt], to_s16x4(st[kt]), o);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) p[r] *= inv;
-                    o = MFMA16(vb[h][kt], to_s16x4(p), o);
-                }
-                const float g = gate[qt][h];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] *= g;
+                for (int r = 0; r < 4; ++r) o[r] *= scale;
                 const s16x4 ob = to_s16x4(o);
 #pragma unroll
-                for (int ot = 0; ot < 4; ++ot) out[ot][qt] = MFMA16(wo[ot][h], ob, out[ot][qt]);
+                for (int ot = 0; ot < 4; ++ot) out[ot][qt] = MFMA16(frag16(ot * HEADS + h), ob, out[ot][qt]);
             }
         }
 
