@@ -45,10 +45,18 @@ def glue():
             L.az_nn_heads_prep.argtypes = [vp, vp, vp, f32, vp, vp, i64, f32, vp]
             L.az_nn_conv_block.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, i64, f32, vp]
             L.az_nn_attn_block.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, f32, vp]
+            L.az_nn_heads.argtypes = [vp, C.POINTER(HeadsWeights), vp, vp, vp, vp, i64, f32, vp]
             _GLUE = L
         except OSError:
             _GLUE = False
     return _GLUE or None
+
+
+class HeadsWeights(C.Structure):
+    """az_nn_heads_weights of include/az_nn.h"""
+    _PTRS = ("p_norm", "p_gate_w", "p_fc_w", "p_fc_b", "p_out_w", "d_pool_norm", "d_pool_w", "d_pool_b", "d_norm",
+             "d_fc_w", "d_fc_b", "d_out_norm", "d_val_w", "d_val_b", "d_aux_w")
+    _fields_ = [(n, C.c_void_p) for n in _PTRS] + [(n, C.c_float) for n in ("p_gate_b", "p_out_b", "d_aux_b", "aux_scale")]
 
 
 class FastConnect4Net(torch.nn.Module):
@@ -120,6 +128,17 @@ class FastConnect4Net(torch.nn.Module):
                     and glue() is not None)
         self.mfma_conv = self.hip and os.environ.get("AZ_NN_MFMA_CONV", "1") != "0"
         self.mfma_attn = self.hip and os.environ.get("AZ_NN_MFMA_ATTN", "1") != "0"
+        self.fused_heads = self.mfma_conv and self.mfma_attn and os.environ.get("AZ_NN_FUSED_HEADS", "1") != "0"
+        self._heads_w = None
+        if self.fused_heads:
+            hw = HeadsWeights()
+            for n in HeadsWeights._PTRS:
+                setattr(hw, n, getattr(self, n).data_ptr())
+            hw.p_gate_b = self.p_gate_b_host
+            hw.p_out_b = float(self.p_out_b.reshape(-1)[0].item())
+            hw.d_aux_b = float(self.d_aux_b.reshape(-1)[0].item())
+            hw.aux_scale = float(self.aux_target_offset)
+            self._heads_w = hw
 
     @classmethod
     def from_module(cls, net, dtype=torch.bfloat16, device=None):
@@ -157,7 +176,63 @@ class FastConnect4Net(torch.nn.Module):
         return F.conv2d(img, w, None, padding=1).permute(0, 2, 3, 1)         # (B, 6, 7, Cout) view
 
     @torch.no_grad()
+    def predict_device(self, x, action_mask=None):
+        """(probs (B,7), wdl (B,3) relative [draw, win, loss], moves_left (B,)) fp32 on the device:
+        what the reference's `predict` returns (Network.py:267-288) without the host copies."""
+        if not (self.hip and x.is_cuda):
+            lp, v, st = self(x, action_mask)
+            return lp.exp(), v.exp(), st * float(self.aux_target_offset)
+        if not self.fused_heads:
+            lp, v, st = self._forward_hip(x, action_mask)
+            return lp.exp(), v.exp(), st * float(self.aux_target_offset)
+        t, bsz, L, s = self._body_hip(x)
+        probs = torch.empty((bsz, COLS), dtype=torch.float32, device=self.device)
+        wdl = torch.empty((bsz, 3), dtype=torch.float32, device=self.device)
+        ml = torch.empty((bsz,), dtype=torch.float32, device=self.device)
+        m = None
+        if action_mask is not None:
+            m = action_mask if action_mask.dtype in (torch.uint8, torch.bool) else action_mask.to(torch.bool)
+            m = m.contiguous()
+        L.az_nn_heads(t.data_ptr(), C.byref(self._heads_w), None if m is None else m.data_ptr(), probs.data_ptr(),
+                      wdl.data_ptr(), ml.data_ptr(), bsz, 1e-5, s)
+        self._keep_mask = m
+        return probs, wdl, ml
+
+    @torch.no_grad()
     def _forward_hip(self, x, action_mask):
+        if self.mfma_attn and self.mfma_conv:
+            t, bsz, L, s = self._body_hip(x)
+            return self._heads_hip(t, action_mask, bsz, L, s)
+        return self._forward_hip_glue(x, action_mask)
+
+    @torch.no_grad()
+    def _body_hip(self, x):
+        """embedding, stem, residual blocks and attention on the MFMA kernels -> final tokens"""
+        L = glue()
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        bsz = x.shape[0]
+        dev, bf = self.device, torch.bfloat16
+        c_dim = self.h_dim
+        x = x.contiguous().float()
+        t0 = torch.empty((bsz, CELLS, self.embed_dim), dtype=bf, device=dev)
+        L.az_nn_embed(x.data_ptr(), self.emb_own.data_ptr(), self.emb_opp.data_ptr(), self.pos.data_ptr(),
+                      t0.data_ptr(), bsz, self.embed_dim, s)
+        t = torch.empty((bsz, CELLS, c_dim), dtype=bf, device=dev)
+        L.az_nn_conv_block(t0.data_ptr(), self.embed_dim, self.stem_w.data_ptr(), self.stem_b.data_ptr(), None,
+                           None, 0, t.data_ptr(), bsz, 1e-5, s)
+        for w, b, g, beta in self.res:
+            t2 = torch.empty_like(t)
+            L.az_nn_conv_block(t.data_ptr(), c_dim, getattr(self, w).data_ptr(), getattr(self, b).data_ptr(),
+                               getattr(self, g).data_ptr(), getattr(self, beta).data_ptr(), 1, t2.data_ptr(),
+                               bsz, 1e-5, s)
+            t = t2
+        t2 = torch.empty_like(t)
+        L.az_nn_attn_block(t.data_ptr(), self.pre_w.data_ptr(), self.qkvg_w.data_ptr(), self.qn_w.data_ptr(),
+                           self.kn_w.data_ptr(), self.o_w.data_ptr(), t2.data_ptr(), bsz, 1e-5, s)
+        return t2, bsz, L, s
+
+    @torch.no_grad()
+    def _forward_hip_glue(self, x, action_mask):
         L = glue()
         s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         bsz = x.shape[0]
@@ -286,5 +361,5 @@ class FastConnect4Net(torch.nn.Module):
         import numpy as np
         t = torch.as_tensor(np.asarray(state), dtype=torch.float32, device=self.device)
         m = None if action_mask is None else torch.as_tensor(np.asarray(action_mask), device=self.device)
-        lp, v, s = self(t, m)
-        return lp.exp().cpu().numpy(), v.exp().cpu().numpy(), (s * 42.0).view(-1, 1).cpu().numpy()
+        probs, wdl, ml = self.predict_device(t, m)
+        return probs.cpu().numpy(), wdl.cpu().numpy(), ml.view(-1, 1).cpu().numpy()

@@ -154,8 +154,7 @@ class FusedSearch:
         if hasattr(self.net, "predict_device"):
             probs, wdl, ml = self.net.predict_device(features, mask)
         elif self.fast is not None:
-            log_prob, value_lp, steps = self.fast(features, mask)
-            probs, wdl, ml = log_prob.exp(), value_lp.exp(), steps * self.aux_scale
+            probs, wdl, ml = self.fast.predict_device(features, mask_u8)
         else:
             with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.autocast):
                 log_prob, value_lp, steps = self.net(features, action_mask=mask)

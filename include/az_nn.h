@@ -61,6 +61,23 @@ int az_nn_attn_post(const void *attn, const void *gate_sigmoid, void *out, int64
 int az_nn_heads_prep(const void *tokens, const void *p_norm_w, const void *p_gate_w, float p_gate_b,
                      void *col, void *mean, int64_t batch, float eps, void *stream);
 
+/* Both output heads as one kernel (nn_heads.hip): final tokens (batch, 42, 64) ->
+ *   probs (batch, 7) f32       softmax of the column policy head, illegal columns (mask byte 0,
+ *                              mask (batch, 7) uint8 or NULL) filled with -1e9 before the softmax
+ *   wdl (batch, 3) f32         softmax of the value head, RELATIVE order [draw, win, loss]
+ *   moves_left (batch) f32     aux_scale * sigmoid(aux head)
+ * i.e. exactly the three arrays `predict` returns (Network.py:96-141, 267-288) and
+ * az_mcts_dev_backprop consumes.  Weights are bf16 device arrays with the reference's
+ * state-dict shapes ([out][in] row-major linears); the four scalars are host floats. */
+typedef struct az_nn_heads_weights {
+    const void *p_norm, *p_gate_w, *p_fc_w, *p_fc_b, *p_out_w;          /* policy_head.{norm,row_gate,fc,out} */
+    const void *d_pool_norm, *d_pool_w, *d_pool_b, *d_norm, *d_fc_w, *d_fc_b, *d_out_norm;
+    const void *d_val_w, *d_val_b, *d_aux_w;                             /* dual_head.{value_out,aux_out} */
+    float p_gate_b, p_out_b, d_aux_b, aux_scale;
+} az_nn_heads_weights;
+int az_nn_heads(const void *tokens, const az_nn_heads_weights *w, const uint8_t *mask, float *probs, float *wdl,
+                float *moves_left, int64_t batch, float eps, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -291,6 +291,48 @@ def test_mfma_attention_block_matches_torch(env):
         assert err.max().item() < 8e-2 and err.mean().item() < 6e-3, (B, err.max().item(), err.mean().item())
 
 
+def test_fused_heads_kernel_matches_torch_heads(env):
+    """az_nn_heads (nn_heads.hip) against the PyTorch heads of the same twin on random final
+    tokens, with the reference checkpoint's trained weights (non-zero output layers, so every
+    stage matters); ragged batch sizes exercise the grid-stride loop and its prefetch."""
+    torch = env["torch"]
+    import ctypes as C
+    from src.fast_net import FastConnect4Net, glue
+    wts = load("g7_checkpoint_weights")
+    net = env["N"].Connect4Net(device="cuda").eval()
+    env["N"].load_reference_weights(net, {k: wts[k] for k in wts.files})
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    fast = FastConnect4Net.from_module(net)
+    assert fast.fused_heads
+    L = glue()
+    for B in (1, 3, 777, 4099):
+        tok = (torch.randn((B, 42, 64), device="cuda", generator=gen) * 1.5).to(torch.bfloat16)
+        mask = torch.rand((B, 7), device="cuda", generator=gen) > 0.25
+        mask[:, 3] = True
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        lp, lv, st = fast._heads_hip(tok, mask, B, L, s)
+        probs = torch.empty((B, 7), dtype=torch.float32, device="cuda")
+        wdl = torch.empty((B, 3), dtype=torch.float32, device="cuda")
+        ml = torch.empty((B,), dtype=torch.float32, device="cuda")
+        m8 = mask.to(torch.uint8).contiguous()
+        assert L.az_nn_heads(tok.data_ptr(), C.byref(fast._heads_w), m8.data_ptr(), probs.data_ptr(), wdl.data_ptr(),
+                             ml.data_ptr(), B, 1e-5, s) == 0
+        torch.cuda.synchronize()
+        assert torch.isfinite(probs).all() and torch.isfinite(wdl).all() and torch.isfinite(ml).all()
+        assert (probs[~mask] == 0).all()
+        assert (probs.sum(1) - 1).abs().max().item() < 1e-5 and (wdl.sum(1) - 1).abs().max().item() < 1e-5
+        ep, ew, em = (probs - lp.exp()).abs(), (wdl - lv.exp()).abs(), (ml - st * 42.0).abs()
+        assert ep.max().item() < 3e-2 and ep.mean().item() < 2e-3, (B, ep.max().item(), ep.mean().item())
+        assert ew.max().item() < 3e-2 and ew.mean().item() < 2e-3, (B, ew.max().item(), ew.mean().item())
+        assert em.max().item() < 0.5, (B, em.max().item())
+    # no mask = every column legal
+    assert L.az_nn_heads(tok.data_ptr(), C.byref(fast._heads_w), None, probs.data_ptr(), wdl.data_ptr(),
+                         ml.data_ptr(), B, 1e-5, s) == 0
+    lp, _, _ = fast._heads_hip(tok, None, B, L, s)
+    torch.cuda.synchronize()
+    assert (probs - lp.exp()).abs().max().item() < 3e-2
+
+
 def test_fast_net_hip_path_equals_torch_path(env):
     torch = env["torch"]
     from src.fast_net import FastConnect4Net
