@@ -29,13 +29,18 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 
 #include "az_nn.h"
 
 namespace {
 
 constexpr int CELLS = 42, COLS = 7;
-constexpr int PCOLS = 9, PCELLS = 72;          // zero-padded 8 x 9 image
+// Zero-padded image with a row pitch of 8 cells: the right halo of a row IS the left halo of the
+// next one (both zero), so cell p = (r+1)*8 + (c+1) and p & 7 - the swizzle key - depends on the
+// column only: the three rows of a 3x3 window are the same address +- 1 KiB.
+constexpr int PCOLS = 8, PCELLS = 72;          // 65 cells used
 constexpr int TS = 4;                          // samples per tile = wavefronts per workgroup
 constexpr int TROWS = TS * CELLS;              // 168 tokens
 constexpr int MT = (TROWS + 15) / 16;          // 11 token tiles, the last one half full
@@ -70,6 +75,33 @@ __device__ __forceinline__ V8 pack8(const float f[8])
     for (int i = 0; i < 4; ++i) v.w[i] = pack2(f[2 * i], f[2 * i + 1]);
     return v;
 }
+// wave-wide sum on the DPP network (the adds carry the lane movement as an operand modifier):
+// 8 VALU instructions and a readlane, against 6 x (ds_bpermute + address + add) for xor-shuffles
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+    v += dpp_mov<0xB1>(v);           // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);           // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);          // row_half_mirror
+    v += dpp_mov<0x140>(v);          // row_mirror: every lane of a 16-lane row holds the row sum
+    v += dpp_mov<0x142, 0xa>(v);     // row_bcast:15 into rows 1 and 3
+    v += dpp_mov<0x143, 0xc>(v);     // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// packed-f32 arithmetic (v_pk_mul/add/fma_f32): two elements per VALU instruction
+__device__ __forceinline__ f32x2 unpack2(uint32_t w) { return f32x2{bf_lo(w), bf_hi(w)}; }
+__device__ __forceinline__ f32x2 silu2(f32x2 x)
+{
+    const f32x2 t = x * f32x2{-1.44269504f, -1.44269504f};
+    const f32x2 e = f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + f32x2{1.0f, 1.0f};
+    return x * f32x2{__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+}
 // x * sigmoid(x) with the hardware exp2 / reciprocal (about 1 ulp each; the result is rounded to
 // bf16 right after).  The IEEE divide costs ~10 instructions per element, and this kernel's
 // elementwise work is issued by only four wavefronts per CU.
@@ -78,11 +110,32 @@ __device__ __forceinline__ float silu(float x)
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x));
 }
 
-// 16 bytes per lane from global memory straight into LDS at (wave-uniform) lds + lane * 16
-__device__ __forceinline__ void glds16(const void *gsrc, uint8_t *lds)
+// 16 bytes per lane from global memory straight into LDS at (wave-uniform) lds_off + lane * 16.
+// Written as inline assembly on purpose: when the compiler knows that a global_load_lds is in
+// flight it puts s_waitcnt vmcnt(0) in front of every later LDS read that might alias it, i.e.
+// at the top of the MFMA phase, and the HBM latency this staging is meant to hide is paid in
+// full.  The kernel orders the accesses itself (vmcnt(0) + barrier before the buffer is read).
+__device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_off)
 {
-    __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void *)lds, 16, 0, 0);
+    uint32_t keep;      // M0 is compiler-reserved: saved and restored inside the statement
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_off) : "memory");
 }
+__device__ __forceinline__ uint32_t lds_addr(const void *p)
+{
+    return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) const void *)p));
+}
+// workgroup barrier that orders LDS traffic only: __syncthreads() would also wait for this
+// wave's outstanding global stores
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// az_nn_debug bit 4: per-wave cycle totals of the phases (s_memtime), read back by az_nn_conv_profile
+__device__ unsigned long long g_prof[2048 * 8];
 
 template <int CIN, bool NORM, bool RESID>
 __global__ void __launch_bounds__(256, 2) k_conv_block(const uint16_t *x, const uint16_t *w, const uint16_t *bias,
@@ -92,34 +145,43 @@ __global__ void __launch_bounds__(256, 2) k_conv_block(const uint16_t *x, const 
     constexpr int K = 9 * CIN;
     constexpr int KSTEPS = K / 32;                // 18 (C_in 64) or 9 (C_in 32)
     constexpr int KPT = CIN / 32;                 // k steps per tap
-    constexpr int VPC = CIN / 8;                  // 16-byte vectors per cell
-    constexpr int VPS = CELLS * VPC;              // vectors per sample
+    constexpr int VPC = CIN / 8;                  // 16-byte vectors per input cell
+    constexpr int VPS = CELLS * VPC;              // vectors per input sample
     constexpr int PER = (VPS + 63) / 64;          // vectors per lane of a sample's wavefront
     constexpr int SB = VPS * 16;                  // bytes per raw sample
+    constexpr int OVPS = CELLS * COUT / 8;        // vectors per output sample
+    constexpr int OPER = (OVPS + 63) / 64;
+    constexpr int OSB = OVPS * 16;                // bytes per output sample
 
     extern __shared__ __align__(16) uint8_t smem[];
     uint8_t *img = smem;                                          // TS * PCELLS * CELLB, swizzled
     uint8_t *rawb = smem + TS * PCELLS * CELLB;                   // 2 x TS x SB: raw tiles, double buffered
-    __shared__ float s_gam[NORM ? CIN : 1], s_bet[NORM ? CIN : 1];
+    uint8_t *outs = rawb + 2 * TS * SB;                           // TS x OSB output tile (unless RESID: in place)
+    // (no static __shared__ objects: the image must sit at LDS address 0 for the compiler to
+    // fold the window's row displacements into the ds_read offset fields)
+    float *s_gam = reinterpret_cast<float *>(outs + (RESID ? 0 : TS * OSB)), *s_bet = s_gam + CIN;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mh = wave & 1, th = wave >> 1;
     const int l15 = lane & 15, l4 = lane >> 4;
 
-    // ---- weights: this wave's A fragments (rows = its 32 output channels), resident for the kernel
+    // ---- weights: this wave's A fragments, resident for the whole kernel.  MFMA row r of m tile
+    // mt stands for output channel 32*mh + 8*(r>>2) + 4*mt + (r&3): with the C layout (rows
+    // 4*(lane>>4)+reg) a lane then ends up with EIGHT CONSECUTIVE channels of its token - chunk
+    // 4*mh + (lane>>4) - i.e. one 16-byte vector of the output row.
     bf16x8 aw[2][KSTEPS];
     float bia[2][4];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-        const int o = mh * 32 + mt * 16 + l15;
+        const int o = mh * 32 + (l15 >> 2) * 8 + mt * 4 + (l15 & 3);
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s)
             aw[mt][s] = *reinterpret_cast<const bf16x8 *>(w + static_cast<size_t>(o) * K + s * 32 + l4 * 8);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            bia[mt][r] = __uint_as_float(static_cast<uint32_t>(bias[mh * 32 + mt * 16 + l4 * 4 + r]) << 16);
+            bia[mt][r] = __uint_as_float(static_cast<uint32_t>(bias[mh * 32 + l4 * 8 + mt * 4 + r]) << 16);
     }
     if (NORM && tid < CIN) {
         s_gam[tid] = __uint_as_float(static_cast<uint32_t>(gamma[tid]) << 16);
@@ -137,20 +199,21 @@ __global__ void __launch_bounds__(256, 2) k_conv_block(const uint16_t *x, const 
     // Raw tiles go from HBM straight into LDS (global_load_lds_dwordx4: no registers held while
     // the previous tile is multiplied).  Wave s stages sample s; an instruction fills 1 KiB in
     // lane order, so slot j of a sample holds cell j / VPC; within a 64-channel cell the chunk
-    // order is XORed with (cell & 7) through the SOURCE address, which spreads the residual reads
-    // of the epilogue over the banks and leaves every lane with one fixed channel chunk in P1.
-    auto swz = [](int cell) { return VPC == 8 ? (cell & 7) : 0; };
+    // order is XORed with (cell & 7) through the SOURCE address.  That is also the layout of the
+    // output tile, so the residual block updates the raw tile in place, and it leaves every
+    // lane with one fixed channel chunk in P1.
+    auto swz_in = [](int cell) { return VPC == 8 ? (cell & 7) : 0; };
+    const uint32_t raw_lds = lds_addr(rawb);
     auto stage_tile = [&](int64_t tile, int buf, int lane) {
         const int64_t b = tile * TS + wave;
         if (b >= B) return;
         const uint16_t *xs = x + b * (CELLS * CIN);
-        uint8_t *dst = rawb + (buf * TS + wave) * SB;
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int s = lane + 64 * i;
             if (s < VPS) {
                 const int cell = s / VPC;
-glds16(xs + (cell * VPC + ((s % VPC) ^ swz(cell))) * 8, dst + i * 1024);
+                glds16(xs + (cell * VPC + ((s % VPC) ^ swz_in(cell))) * 8, raw_lds + (buf * TS + wave) * SB + i * 1024);
             }
         }
     };
@@ -158,21 +221,31 @@ glds16(xs + (cell * VPC + ((s % VPC) ^ swz(cell))) * 8, dst + i * 1024);
     const int64_t ntiles = (B + TS - 1) / TS;
     if (static_cast<int64_t>(blockIdx.x) < ntiles) stage_tile(blockIdx.x, 0, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    lds_barrier();
     int par = 0;
+    const bool prof = dbg & 16;
+    unsigned long long tp[6] = {0, 0, 0, 0, 0, 0}, tl = prof ? __builtin_amdgcn_s_memtime() : 0;
+    auto stamp = [&](int k) {
+        if (prof) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            tp[k] += now - tl;
+            tl = now;
+        }
+    };
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, par ^= 1) {
         const int64_t b0 = tile * TS;
-        const uint8_t *rawt = rawb + par * TS * SB;
-        // Opaque copy of the lane id: everything P1 and the staging derive from it is recomputed
-        // per tile (a few VALU ops) instead of being hoisted out of the tile loop, where ~40
-        // loop-invariant addresses would push the resident weight fragments into scratch.
+        uint8_t *rawt = rawb + par * TS * SB;
+        uint8_t *outt = RESID ? rawt : outs;
+        // Opaque copy of the lane id: everything P1, P3 and the staging derive from it is
+        // recomputed per tile (a few VALU ops) instead of being hoisted out of the tile loop,
+        // where ~40 loop-invariant addresses would push the resident weights into scratch.
         int lane_t = lane;
         asm volatile("" : "+v"(lane_t));
 
         // ---- P1: GroupNorm statistics of this wave's sample (one pass, fp32), then the
         // normalised vectors go to the padded image
         {
-            const int ck = (lane_t % VPC) ^ swz(lane_t / VPC);      // the channel chunk of every slot this lane owns
+            const int ck = (lane_t % VPC) ^ swz_in(lane_t / VPC);   // the channel chunk of every slot this lane owns
             V8 raw[PER];
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
@@ -180,25 +253,28 @@ glds16(xs + (cell * VPC + ((s % VPC) ^ swz(cell))) * 8, dst + i * 1024);
                 if (s < VPS) raw[i] = *reinterpret_cast<const V8 *>(rawt + wave * SB + s * 16);
                 else raw[i].w[0] = raw[i].w[1] = raw[i].w[2] = raw[i].w[3] = 0;
             }
-            float sc[8], sh[8];
+            f32x2 sc[4], sh[4];
             if (NORM) {
-                float sum = 0.0f, sq = 0.0f;
+                f32x2 sum2 = {0.0f, 0.0f}, sq2 = {0.0f, 0.0f};
 #pragma unroll
                 for (int i = 0; i < PER; ++i) {
-                    float f[8];
-                    unpack8(raw[i], f);
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) { sum += f[q]; sq += f[q] * f[q]; }
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x2 f = unpack2(raw[i].w[q]);              // vectors past the sample are zero
+                        sum2 += f;
+                        sq2 = __builtin_elementwise_fma(f, f, sq2);
+                    }
                 }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o, 64); sq += __shfl_xor(sq, o, 64); }
+                const float sum = wave_sum(sum2.x + sum2.y), sq = wave_sum(sq2.x + sq2.y);
                 const float mean = sum * (1.0f / (CELLS * CIN));
                 const float var = fmaxf(sq * (1.0f / (CELLS * CIN)) - mean * mean, 0.0f);
                 const float rstd = rsqrtf(var + eps);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    sc[q] = rstd * s_gam[ck * 8 + q];
-                    sh[q] = s_bet[ck * 8 + q] - mean * sc[q];
+                for (int q = 0; q < 4; ++q) {
+                    const f32x2 gq = *reinterpret_cast<const f32x2 *>(&s_gam[ck * 8 + 2 * q]);
+                    const f32x2 bq = *reinterpret_cast<const f32x2 *>(&s_bet[ck * 8 + 2 * q]);
+                    sc[q] = gq * f32x2{rstd, rstd};
+                    sh[q] = bq - sc[q] * f32x2{mean, mean};
                 }
             }
 #pragma unroll
@@ -210,18 +286,21 @@ glds16(xs + (cell * VPC + ((s % VPC) ^ swz(cell))) * 8, dst + i * 1024);
                     const int p = (r + 1) * PCOLS + (c + 1);
                     V8 out = raw[i];
                     if (NORM) {
-                        float f[8];
-                        unpack8(raw[i], f);
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) f[q] = f[q] * sc[q] + sh[q];
-                        out = pack8(f);
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x2 f = __builtin_elementwise_fma(unpack2(raw[i].w[q]), sc[q], sh[q]);
+                            out.w[q] = pack2(f.x, f.y);
+                        }
                     }
                     *reinterpret_cast<V8 *>(img + (wave * PCELLS + p) * CELLB + ((ck ^ (p & 7)) << 4)) = out;
                 }
             }
         }
-        __syncthreads();
+        stamp(0);
+        lds_barrier();
+        stamp(1);
         // the next tile travels from HBM into the other raw buffer while this one is multiplied
+        // (every wave finished reading that buffer - P3 of the previous tile - before the barrier)
         if (tile + gridDim.x < ntiles) stage_tile(tile + gridDim.x, par ^ 1, lane_t);
 
         // ---- P2: wave (mh, th) multiplies token tiles [6*th, 6*th+6) two at a time
@@ -239,19 +318,34 @@ glds16(xs + (cell * VPC + ((s % VPC) ^ swz(cell))) * 8, dst + i * 1024);
                 pc[u] = smp * PCELLS + (r + 1) * PCOLS + (c + 1);
                 if (t0 + u >= MT) row[u] = TROWS;                   // nothing to store
             }
-            f32x4 acc[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
-            // B fragments of one tap: cell p = centre + tap offset (PCELLS is a multiple of 8, so
-            // p & 7 is the swizzle key); chunk 4*ks + l4, i.e. the second half of the cell is the
-            // first with address bit 6 flipped
-            auto fetch = [&](int tap, bf16x8 (&xf)[2][KPT]) {
-                const int off = (tap / 3 - 1) * PCOLS + (tap % 3 - 1);
+            // the accumulators start at the bias
+            f32x4 acc[2][2];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int p = pc[u] + off;
-                    const uint32_t a0 = static_cast<uint32_t>(p * CELLB + ((l4 ^ (p & 7)) << 4));
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int ks = 0; ks < KPT; ++ks) xf[u][ks] = *reinterpret_cast<const bf16x8 *>(img + (a0 ^ (ks << 6)));
+                for (int mt = 0; mt < 2; ++mt) acc[u][mt] = f32x4{bia[mt][0], bia[mt][1], bia[mt][2], bia[mt][3]};
+            // B fragments: three swizzled column addresses per token tile (dx = -1, 0, +1; key =
+            // cell & 7), each serving the three rows of the window at -1 KiB, 0, +1 KiB; chunk
+            // 4*ks + l4, i.e. the second half of the cell is the first with address bit 6 flipped
+            uint32_t col[2][3][KPT];            // row above the window (p >= 8: never below the image)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const uint32_t p = static_cast<uint32_t>(pc[u] + d - 1 - PCOLS);
+                    // (the mask tells the compiler the offset is small and non-negative, which is
+                    // what lets it put the row displacement into the ds_read offset field)
+                    const uint32_t o = (p * CELLB + ((l4 ^ (p & 7)) << 4)) & 0xffffu;
+#pragma unroll
+                    for (int ks = 0; ks < KPT; ++ks) col[u][d][ks] = o ^ (ks << 6);
                 }
+            auto fetch = [&](int tap, bf16x8 (&xf)[2][KPT]) {
+                const int dy = tap / 3, d = tap % 3;
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int ks = 0; ks < KPT; ++ks)
+                        xf[u][ks] = *reinterpret_cast<const bf16x8 *>(&smem[col[u][d][ks] + dy * PCOLS * CELLB]);   // img = smem + 0
             };
             // one tap ahead: the reads of tap+1 are issued before the MFMAs of tap, and the
             // scheduling barrier keeps the compiler from hoisting all 36 reads (144 VGPRs) to the top
@@ -272,33 +366,51 @@ glds16(xs + (cell * VPC + ((s % VPC) ^ swz(cell))) * 8, dst + i * 1024);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // C layout: column = token (lane & 15), rows = output channels 4*(lane>>4)+reg of the m tile
+            // epilogue on the accumulators: this lane holds channels 8*(4*mh+l4) .. +7 of token
+            // (lane & 15): bias, SiLU, residual, and the vector goes to the output tile in LDS
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 if (row[u] >= TROWS || (dbg & 2)) continue;
                 const int smp = row[u] / CELLS, cell = row[u] - smp * CELLS;
-                if (b0 + smp >= B) continue;
-                uint16_t *yt = y + (b0 * CELLS + row[u]) * COUT;
+                V8 *slot = reinterpret_cast<V8 *>(outt + smp * OSB + cell * 128 + (((mh * 4 + l4) ^ (cell & 7)) << 4));
+                V8 rr;
+                if (RESID) rr = *slot;
+                V8 o;
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    uint32_t lo = pack2(silu(acc[u][mt][0] + bia[mt][0]), silu(acc[u][mt][1] + bia[mt][1]));
-                    uint32_t hi = pack2(silu(acc[u][mt][2] + bia[mt][2]), silu(acc[u][mt][3] + bia[mt][3]));
-                    if (RESID) {
-                        const int chunk = mh * 4 + mt * 2 + (l4 >> 1);
-                        const uint2 rr = *reinterpret_cast<const uint2 *>(
-                            rawt + smp * SB + cell * 128 + ((chunk ^ swz(cell)) << 4) + (l4 & 1) * 8);
-                        lo = pack2(bf_lo(lo) + bf_lo(rr.x), bf_hi(lo) + bf_hi(rr.x));
-                        hi = pack2(bf_lo(hi) + bf_lo(rr.y), bf_hi(hi) + bf_hi(rr.y));
-                    }
-                    uint2 o; o.x = lo; o.y = hi;
-                    *reinterpret_cast<uint2 *>(yt + mh * 32 + mt * 16 + l4 * 4) = o;
+                for (int q = 0; q < 4; ++q) {
+                    f32x2 v = silu2(f32x2{acc[u][q >> 1][2 * (q & 1)], acc[u][q >> 1][2 * (q & 1) + 1]});
+                    if (RESID) v += unpack2(rr.w[q]);
+                    o.w[q] = pack2(v.x, v.y);
+                }
+                *slot = o;
+            }
+        }
+        // the staged tile has landed; every wave is done with img and has written its outputs
+        stamp(2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(3);
+        lds_barrier();
+        stamp(4);
+
+        // ---- P3: the output tile leaves as whole 128-byte rows (wave = sample, 16 bytes per lane)
+        if (b0 + wave < B && !(dbg & 2)) {
+            uint16_t *ys = y + (b0 + wave) * (CELLS * COUT);
+#pragma unroll
+            for (int i = 0; i < OPER; ++i) {
+                const int s = lane_t + 64 * i;
+                if (s < OVPS) {
+                    const int cell = s >> 3;
+                    const V8 v = *reinterpret_cast<const V8 *>(outt + wave * OSB + s * 16);
+                    *reinterpret_cast<V8 *>(ys + cell * COUT + (((s & 7) ^ (cell & 7)) << 3)) = v;
                 }
             }
         }
-        // the staged tile has landed, and every wave is done with img / this raw buffer
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        // (the next tile's P1 writes img and reads the other raw buffer; its barrier orders these
+        // reads of the output tile before the staging that overwrites it)
+        stamp(5);
     }
+    if (prof && lane == 0 && blockIdx.x < 512)
+        for (int k = 0; k < 6; ++k) g_prof[(blockIdx.x * 4 + wave) * 8 + k] = tp[k];
 }
 
 int g_dbg = 0;   // timing experiments only (az_nn_debug): 1 skips the MFMA loop, 2 skips the store
@@ -307,7 +419,8 @@ template <int CIN, bool NORM, bool RESID>
 int launch(const void *x, const void *w, const void *bias, const void *gamma, const void *beta, void *y, int64_t B,
            float eps, hipStream_t s)
 {
-    constexpr size_t smem = static_cast<size_t>(TS) * PCELLS * CELLB + 2 * static_cast<size_t>(TS) * CELLS * CIN * 2;
+    constexpr size_t smem = static_cast<size_t>(TS) * PCELLS * CELLB + 2 * static_cast<size_t>(TS) * CELLS * CIN * 2 +
+                            (RESID ? 0 : static_cast<size_t>(TS) * CELLS * COUT * 2) + 2 * CIN * sizeof(float);
     static bool attr_set = false;
     auto kern = k_conv_block<CIN, NORM, RESID>;
     if (!attr_set) {
@@ -315,9 +428,15 @@ int launch(const void *x, const void *w, const void *bias, const void *gamma, co
                                 static_cast<int>(smem)) != hipSuccess)
             return 2;
         attr_set = true;
+        if (getenv("AZ_NN_VERBOSE") != nullptr) {
+            int per_cu = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), 256, smem);
+            fprintf(stderr, "[az_nn] conv block C_in=%d: %zu B LDS, %d workgroups per CU\n", CIN, smem, per_cu);
+        }
     }
     const int64_t ntiles = (B + TS - 1) / TS;
-    const unsigned grid = static_cast<unsigned>(ntiles < 512 ? ntiles : 512);     // two workgroups per CU
+    static const int64_t max_grid = getenv("AZ_NN_CONV_GRID") ? atoll(getenv("AZ_NN_CONV_GRID")) : 512;   // two workgroups per CU
+    const unsigned grid = static_cast<unsigned>(ntiles < max_grid ? ntiles : max_grid);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, static_cast<const uint16_t *>(x),
                        static_cast<const uint16_t *>(w), static_cast<const uint16_t *>(bias),
                        static_cast<const uint16_t *>(gamma), static_cast<const uint16_t *>(beta),
@@ -330,6 +449,12 @@ int launch(const void *x, const void *w, const void *bias, const void *gamma, co
 extern "C" {
 
 int az_nn_debug(int flags) { g_dbg = flags; return 0; }
+
+int az_nn_conv_profile(unsigned long long *out, int n)
+{
+    if (n > 2048 * 8) n = 2048 * 8;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * n) == hipSuccess ? 0 : 2;
+}
 
 int az_nn_conv_block(const void *x, int c_in, const void *weight_ohwi, const void *bias, const void *gamma,
                      const void *beta, int residual, void *y, int64_t batch, float eps, void *stream)

@@ -44,8 +44,12 @@ int az_nn_conv_block(const void *x, int c_in, const void *weight_ohwi, const voi
  * 0-63 Q, 64-127 K, 128-191 V, 192-195 gate; o_w (64, 64) [out][in]; 4 heads of 16. */
 int az_nn_attn_block(const void *x, const void *prenorm_w, const void *qkvg_w, const void *q_norm_w,
                      const void *k_norm_w, const void *o_w, void *y, int64_t batch, float eps, void *stream);
-/* timing experiments: bit 0 skips the MFMA loop of az_nn_conv_block, bit 1 its store phase */
+/* timing experiments on az_nn_conv_block: bit 0 skips its MFMA phase, bit 1 its epilogue and
+ * stores, bit 4 records per-wavefront cycle totals of its phases (az_nn_conv_profile: 8 values
+ * per wavefront - P1, barrier, MFMA + epilogue, staging wait, barrier, store - for the first
+ * n / 8 wavefronts of the last launch). */
 int az_nn_debug(int flags);
+int az_nn_conv_profile(unsigned long long *out, int n);
 /* nn.RMSNorm over the last dimension of 64 */
 int az_nn_rmsnorm64(const void *x, const void *w, void *y, int64_t rows, float eps, void *stream);
 /* qkvg (batch*42, row_len) with row_len 196 or 200 (3*64 q|k|v, 4 gate logits, optional zero
