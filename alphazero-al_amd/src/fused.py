@@ -16,6 +16,8 @@ With use_symmetry=False and dirichlet_alpha<=0 nothing random is consumed and th
 bit-identical to the host path (tests/test_fused_gpu.py).
 """
 import ctypes as C
+import gc
+import weakref
 import os
 
 import numpy as np
@@ -106,7 +108,12 @@ class FusedSearch:
 
     def __init__(self, wrapper, net):
         require_single_hip_runtime()
-        self.w = wrapper
+        # no reference cycle with the wrapper (which owns this object): an engine must be freed by
+        # reference counting, never by a cyclic-GC pass that happens to run inside a graph capture
+        self._w = weakref.ref(wrapper)
+        self.mcts = wrapper.mcts
+        self.board_shape = tuple(wrapper.board_shape)
+        self.game_name = wrapper._game_name
         self.net = net
         self.h = C.c_void_p(wrapper.mcts.handle)
         self.B = wrapper.batch_size
@@ -144,7 +151,7 @@ class FusedSearch:
     def _buffers(self, K):
         if K not in self._bufs:
             n = self.B * K
-            self._bufs[K] = (torch.empty((n, 3) + tuple(self.w.board_shape), dtype=torch.float32, device=self.device),
+            self._bufs[K] = (torch.empty((n, 3) + self.board_shape, dtype=torch.float32, device=self.device),
                              torch.empty((n, self.A), dtype=torch.uint8, device=self.device))
         return self._bufs[K]
 
@@ -161,7 +168,7 @@ class FusedSearch:
             probs = log_prob.float().exp()
             wdl = value_lp.exp().float()
             ml = (steps * self.aux_scale).float()
-            if self.w._game_name == "Othello":
+            if self.game_name == "Othello":
                 # the Othello head predicts a disc difference; the search consumes its utility
                 # (Othello/Network.py:247-249)
                 scale = float(getattr(self.net, "score_scale", 8.0))
@@ -178,7 +185,7 @@ class FusedSearch:
         return probs, wdl, ml      # keep alive until enqueued work is ordered behind them
 
     def _cfg_key(self):
-        c = self.w.mcts.config
+        c = self.mcts.config
         return (c.c_init, c.c_base, c.dirichlet_alpha, c.noise_epsilon, c.fpu_reduction, c.mlh_slope,
                 c.mlh_cap, c.value_decay, bool(c.use_symmetry), c.vl_count)
 
@@ -203,8 +210,17 @@ class FusedSearch:
             del self._graphs[k]
         g = torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
-        with torch.cuda.graph(g):
-            outs = self._iteration(K, vl)
+        # Nothing may free device memory or synchronise while the stream is capturing: a garbage
+        # collection that finalises some other engine or graph in there aborts the process.
+        gc_was_on = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        try:
+            with torch.cuda.graph(g):
+                outs = self._iteration(K, vl)
+        finally:
+            if gc_was_on:
+                gc.enable()
         self._graphs[key] = g
         self._graph_outs = getattr(self, "_graph_outs", {})
         self._graph_outs[key] = outs
