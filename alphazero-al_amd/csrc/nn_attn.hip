@@ -1,4 +1,4 @@
-// nn_attn.hip - the evaluator's gated attention block as ONE MFMA kernel, no LDS.
+// nn_attn.hip - the evaluator's gated attention block as ONE MFMA kernel.
 //
 //   y = x + o_proj( sigmoid(gate) * softmax(q_norm(Q) k_norm(K)^T / sqrt(16)) V )
 //   with [Q | K | V | gate] = qkvg_proj(RMSNorm(x))                     (Network.py:51-93)
@@ -35,6 +35,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct alignas(16) V8 { uint32_t w[4]; };
 struct alignas(8) V4 { uint32_t w[2]; };
 
@@ -49,6 +50,7 @@ __device__ __forceinline__ uint32_t pack2(float a, float b)
 {
     return static_cast<uint32_t>(to_bf16(a)) | (static_cast<uint32_t>(to_bf16(b)) << 16);
 }
+__device__ __forceinline__ f32x2 unpack2(uint32_t w) { return f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; }
 __device__ __forceinline__ s16x4 to_s16x4(const f32x4 &v)
 {
     union { uint32_t u[2]; s16x4 s; } r;
@@ -118,14 +120,20 @@ __global__ void __launch_bounds__(256, 2) k_attn_block(const uint16_t *x, const 
         r.v = s_w16[f * 64 + lane];
         return r.s;
     };
-    float pw[2][8];                           // prenorm weight of this lane's 16 input channels
+    f32x2 pw[2][4];                           // prenorm weight of this lane's 16 input channels
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pw[s][j] = bf1(pre_w + 32 * s + 8 * l4 + j);
-    float qnw[4], knw[4];                     // per-head norm weights of this lane's rows d = 4*l4 + r
+        for (int j = 0; j < 4; ++j) pw[s][j] = f32x2{bf1(pre_w + 32 * s + 8 * l4 + 2 * j), bf1(pre_w + 32 * s + 8 * l4 + 2 * j + 1)};
+    // per-head norm weights of this lane's rows d = 4*l4 + r.  The 1/sqrt(16) of the scores and
+    // the log2(e) of their softmax ride on q: the scores come out of the MFMA ready for exp2.
+    constexpr float QSCALE = 0.25f * 1.44269504f;
+    f32x2 qnw[2], knw[2];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { qnw[r] = bf1(qn_w + 4 * l4 + r); knw[r] = bf1(kn_w + 4 * l4 + r); }
+    for (int r = 0; r < 2; ++r) {
+        qnw[r] = f32x2{bf1(qn_w + 4 * l4 + 2 * r) * QSCALE, bf1(qn_w + 4 * l4 + 2 * r + 1) * QSCALE};
+        knw[r] = f32x2{bf1(kn_w + 4 * l4 + 2 * r), bf1(kn_w + 4 * l4 + 2 * r + 1)};
+    }
 
     const int64_t stride = static_cast<int64_t>(gridDim.x) * 4;
     for (int64_t b = static_cast<int64_t>(blockIdx.x) * 4 + wave; b < B; b += stride) {
@@ -136,25 +144,27 @@ __global__ void __launch_bounds__(256, 2) k_attn_block(const uint16_t *x, const 
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt) {
             const int tok = tt * 16 + l15;
-            float f[2][8];
-            float ss = 0.0f;
+            f32x2 f[2][4], ss2 = {0.0f, 0.0f};
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 V8 v; v.w[0] = v.w[1] = v.w[2] = v.w[3] = 0;
                 if (tok < CELLS) v = *reinterpret_cast<const V8 *>(xs + tok * C + 32 * s + 8 * l4);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { f[s][2 * i] = bf_lo(v.w[i]); f[s][2 * i + 1] = bf_hi(v.w[i]); }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) ss += f[s][j] * f[s][j];
+                for (int i = 0; i < 4; ++i) {
+                    f[s][i] = unpack2(v.w[i]);
+                    ss2 = __builtin_elementwise_fma(f[s][i], f[s][i], ss2);
+                }
             }
-            ss = col_sum(ss);
+            const float ss = col_sum(ss2.x + ss2.y);
             const float r = rsqrtf(ss * (1.0f / C) + eps);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 V8 o;
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    o.w[i] = pack2(f[s][2 * i] * r * pw[s][2 * i], f[s][2 * i + 1] * r * pw[s][2 * i + 1]);
+                for (int i = 0; i < 4; ++i) {
+                    const f32x2 hv = f[s][i] * f32x2{r, r} * pw[s][i];
+                    o.w[i] = pack2(hv.x, hv.y);
+                }
                 hf[tt][s] = as_bf16x8(o);
             }
         }
@@ -193,14 +203,15 @@ __global__ void __launch_bounds__(256, 2) k_attn_block(const uint16_t *x, const 
                 f32x4 v = MFMA32(hf[tt][0], frag32(16 + h * 2), zero);
                 v = MFMA32(hf[tt][1], frag32(16 + h * 2 + 1), v);
                 // per-(token, head) RMSNorm over d: rows of the column this lane sits in
-                float qs = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
-                float ks = k[0] * k[0] + k[1] * k[1] + k[2] * k[2] + k[3] * k[3];
-                qs = col_sum(qs); ks = col_sum(ks);
+                f32x2 q2[2] = {{q[0], q[1]}, {q[2], q[3]}}, k2[2] = {{k[0], k[1]}, {k[2], k[3]}};
+                const f32x2 qq = __builtin_elementwise_fma(q2[1], q2[1], q2[0] * q2[0]);
+                const f32x2 kk = __builtin_elementwise_fma(k2[1], k2[1], k2[0] * k2[0]);
+                const float qs = col_sum(qq.x + qq.y), ks = col_sum(kk.x + kk.y);
                 const float qr = rsqrtf(qs * (1.0f / HD) + eps), kr = rsqrtf(ks * (1.0f / HD) + eps);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { q[r] = q[r] * qr * qnw[r]; k[r] = k[r] * kr * knw[r]; }
-                qb[tt] = to_s16x4(q);
-                kb[tt] = to_s16x4(k);
+                for (int r = 0; r < 2; ++r) { q2[r] = q2[r] * f32x2{qr, qr} * qnw[r]; k2[r] = k2[r] * f32x2{kr, kr} * knw[r]; }
+                qb[tt] = to_s16x4(f32x4{q2[0].x, q2[0].y, q2[1].x, q2[1].y});
+                kb[tt] = to_s16x4(f32x4{k2[0].x, k2[0].y, k2[1].x, k2[1].y});
                 vb[tt] = to_s16x4(v);
             }
 #pragma unroll
@@ -210,11 +221,10 @@ __global__ void __launch_bounds__(256, 2) k_attn_block(const uint16_t *x, const 
                 float m = -INFINITY;
 #pragma unroll
                 for (int kt = 0; kt < TT; ++kt) {
-                    st[kt] = MFMA16(kb[kt], qb[qt], zero);
+                    st[kt] = MFMA16(kb[kt], qb[qt], zero);          // already in log2 units (QSCALE)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int key = kt * 16 + 4 * l4 + r;
-                        st[kt][r] = key < CELLS ? st[kt][r] * 0.25f : -INFINITY;       // 1/sqrt(16)
+                        if (kt == TT - 1 && kt * 16 + 4 * l4 + r >= CELLS) st[kt][r] = -INFINITY;   // padding keys
                         m = fmaxf(m, st[kt][r]);
                     }
                 }
@@ -224,7 +234,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_block(const uint16_t *x, const 
                 for (int kt = 0; kt < TT; ++kt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        st[kt][r] = __builtin_amdgcn_exp2f((st[kt][r] - m) * 1.44269504f);
+                        st[kt][r] = __builtin_amdgcn_exp2f(st[kt][r] - m);
                         den += st[kt][r];
                     }
                 den = col_sum(den);
