@@ -46,9 +46,12 @@ __device__ __forceinline__ uint16_t to_bf16(float a)
     const __hip_bfloat16 x = __float2bfloat16(a);
     return *reinterpret_cast<const uint16_t *>(&x);
 }
+// one v_cvt_pk_bf16_f32 (round to nearest even, NaN preserving)
 __device__ __forceinline__ uint32_t pack2(float a, float b)
 {
-    return static_cast<uint32_t>(to_bf16(a)) | (static_cast<uint32_t>(to_bf16(b)) << 16);
+    typedef float pk_f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 pk_bf16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(pk_f32x2{a, b}, pk_bf16x2));
 }
 __device__ __forceinline__ f32x2 unpack2(uint32_t w) { return f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; }
 __device__ __forceinline__ s16x4 to_s16x4(const f32x4 &v)
@@ -229,14 +232,19 @@ __global__ void __launch_bounds__(256, 2) k_attn_block(const uint16_t *x, const 
                     }
                 }
                 m = col_max(m);
-                float den = 0.0f;
+                f32x2 den2 = {0.0f, 0.0f};
+                const f32x2 nm = {-m, -m};
 #pragma unroll
                 for (int kt = 0; kt < TT; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        st[kt][r] = __builtin_amdgcn_exp2f(st[kt][r] - m);
-                        den += st[kt][r];
+                    for (int r = 0; r < 4; r += 2) {
+                        const f32x2 d = f32x2{st[kt][r], st[kt][r + 1]} + nm;
+                        const f32x2 e = {__builtin_amdgcn_exp2f(d.x), __builtin_amdgcn_exp2f(d.y)};
+                        st[kt][r] = e.x;
+                        st[kt][r + 1] = e.y;
+                        den2 += e;
                     }
+                float den = den2.x + den2.y;
                 den = col_sum(den);
                 // normalise after the product: O^T = (V^T . E^T) / den, one scale per output element
                 const float gq = h == 0 ? gate[qt][0] : (h == 1 ? gate[qt][1] : (h == 2 ? gate[qt][2] : gate[qt][3]));

@@ -49,9 +49,12 @@ __device__ __forceinline__ uint16_t to_bf16(float a)
     const __hip_bfloat16 x = __float2bfloat16(a);
     return *reinterpret_cast<const uint16_t *>(&x);
 }
+// one v_cvt_pk_bf16_f32 (round to nearest even, NaN preserving)
 __device__ __forceinline__ uint32_t pack2(float a, float b)
 {
-    return static_cast<uint32_t>(to_bf16(a)) | (static_cast<uint32_t>(to_bf16(b)) << 16);
+    typedef float pk_f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 pk_bf16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(pk_f32x2{a, b}, pk_bf16x2));
 }
 __device__ __forceinline__ f32x2 rbf2(f32x2 v) { return unpack2(pack2(v.x, v.y)); }       // round to bf16 and back
 __device__ __forceinline__ bf16x8 as_bf16x8(const V8 &v)
