@@ -42,8 +42,6 @@ constexpr int CELLS = 42, COLS = 7;
 // column only: the three rows of a 3x3 window are the same address +- 1 KiB.
 constexpr int PCOLS = 8, PCELLS = 72;          // 65 cells used
 constexpr int TS = 4;                          // samples per tile = wavefronts per workgroup
-constexpr int TROWS = TS * CELLS;              // 168 tokens
-constexpr int MT = (TROWS + 15) / 16;          // 11 token tiles, the last one half full
 constexpr int COUT = 64;
 constexpr int CELLB = 128;                     // bytes per image cell (C_in 32 uses half of it)
 
@@ -163,6 +161,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_block(const uint16_t *x, const 
     // (no static __shared__ objects: the image must sit at LDS address 0 for the compiler to
     // fold the window's row displacements into the ds_read offset fields)
     float *s_gam = reinterpret_cast<float *>(outs + (RESID ? 0 : TS * OSB)), *s_bet = s_gam + CIN;
+    uint8_t *dump = reinterpret_cast<uint8_t *>(s_gam + 2 * CIN);         // 4 x 8 x 16 B: results of dummy tokens
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -306,86 +305,114 @@ __global__ void __launch_bounds__(256, 2) k_conv_block(const uint16_t *x, const 
         // (every wave finished reading that buffer - P3 of the previous tile - before the barrier)
         if (tile + gridDim.x < ntiles) stage_tile(tile + gridDim.x, par ^ 1, lane_t);
 
-        // ---- P2: wave (mh, th) multiplies token tiles [6*th, 6*th+6) two at a time
-#pragma unroll 1
-        for (int pr = 0; pr < ((dbg & 1) ? 0 : 3); ++pr) {
-            const int t0 = th * 6 + pr * 2;
-            int row[2], pc[2];
+        // ---- P2: wave (mh, th) owns samples 2*th and 2*th+1 of the tile, each as three token
+        // tiles of 16 over a 6 x 8 token grid: token t sits at image cell t + 9, its 8th column is
+        // the halo cell (a dummy token whose result is dropped), so a tile's cells are
+        // consecutive - every B-fragment read is bank-conflict free and needs no division.
+        // The loop is software pipelined by one tile: the epilogue of tile i-1 (VALU) is issued
+        // inside the MFMA stream of tile i, where an MFMA leaves half of its 16 issue cycles free.
+        auto tile_cols = [&](int it, uint32_t (&col)[3][KPT]) {
+            const int smp = 2 * th + it / 3;
+            const uint32_t pc = static_cast<uint32_t>(smp * PCELLS + (it % 3) * 16 + l15 + 9 - PCOLS - 1);   // row above, dx = -1
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int t = t0 + u < MT ? t0 + u : t0;           // the 12th tile does not exist
-                row[u] = t * 16 + l15;
-                const int rc = row[u] < TROWS ? row[u] : TROWS - 1;
-                const int smp = rc / CELLS, cell = rc - smp * CELLS;
-                const int r = cell / COLS, c = cell - r * COLS;
-                pc[u] = smp * PCELLS + (r + 1) * PCOLS + (c + 1);
-                if (t0 + u >= MT) row[u] = TROWS;                   // nothing to store
+            for (int d = 0; d < 3; ++d) {
+                const uint32_t p = pc + d;
+                const uint32_t o = (p * CELLB + ((l4 ^ (p & 7)) << 4)) & 0xffffu;
+#pragma unroll
+                for (int ks = 0; ks < KPT; ++ks) col[d][ks] = o ^ (ks << 6);
             }
-            // the accumulators start at the bias
-            f32x4 acc[2][2];
+        };
+        auto fetch = [&](const uint32_t (&col)[3][KPT], int tap, bf16x8 (&xf)[KPT]) {
+            const int dy = tap / 3, d = tap % 3;
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int ks = 0; ks < KPT; ++ks)
+                xf[ks] = *reinterpret_cast<const bf16x8 *>(&smem[col[d][ks] + dy * PCOLS * CELLB]);   // img = smem + 0
+        };
+        // Epilogue of one token tile on its accumulators, cut into 36 single-instruction steps so
+        // that it can be issued INSIDE the next tile's MFMA stream.  This lane holds channels
+        // 8*(4*mh+l4) .. +7 of token (lane & 15): the bias is already in; SiLU, residual, and the
+        // vector goes to the output tile in LDS (dummy tokens: to a scratch slot).
+        struct Epi { V8 *slot; V8 rr, o; f32x2 t, v; };
+        auto epi_begin = [&](int it, Epi &e) {
+            const int smp = 2 * th + it / 3, t = (it % 3) * 16 + l15;
+            const int cell = (t >> 3) * COLS + (t & 7);
+            // branch-free on purpose: a branch would end the scheduling region
+            const uint32_t m = (t & 7) == 7 ? 0xffffffffu : 0u;
+            const uint32_t off_real = static_cast<uint32_t>(outt - smem) + smp * OSB + cell * 128 + (((mh * 4 + l4) ^ (cell & 7)) << 4);
+            const uint32_t off_dump = static_cast<uint32_t>(dump - smem) + (wave * 8 + (l15 >> 3) + 2 * l4) * 16;
+            e.slot = reinterpret_cast<V8 *>(&smem[(off_real & ~m) | (off_dump & m)]);
+            if (RESID) e.rr = *e.slot;
+        };
+        auto epi_step = [&](int step, const f32x4 (&acc)[2], Epi &e) {       // step 0..35, constant after unrolling
+            const int q = step / 9;
+            const f32x2 x = {acc[q >> 1][2 * (q & 1)], acc[q >> 1][2 * (q & 1) + 1]};
+            switch (step % 9) {
+            case 0: e.t = x * f32x2{-1.44269504f, -1.44269504f}; break;
+            case 1: e.t.x = __builtin_amdgcn_exp2f(e.t.x); break;
+            case 2: e.t.y = __builtin_amdgcn_exp2f(e.t.y); break;
+            case 3: e.t += f32x2{1.0f, 1.0f}; break;
+            case 4: e.t.x = __builtin_amdgcn_rcpf(e.t.x); break;
+            case 5: e.t.y = __builtin_amdgcn_rcpf(e.t.y); break;
+            case 6: e.v = x * e.t; break;
+            case 7: if (RESID) e.v += unpack2(e.rr.w[q]); break;
+            default: e.o.w[q] = pack2(e.v.x, e.v.y); break;
+            }
+        };
+        auto epi_end = [&](Epi &e) { *e.slot = e.o; };
+
+        // One pipelined block: the 36 (18) MFMAs of token tile `it` (B fragments read one tap
+        // ahead), each followed by one or two epilogue steps of the previous tile.  The
+        // scheduling barriers pin that order: a wave issues in order, so a VALU instruction
+        // hides in an MFMA's free issue cycles only if it sits right behind it in the stream.
+        auto block = [&](int it, f32x4 (&acc)[2], bool with_epi, const f32x4 (&pacc)[2]) {
+            uint32_t col[3][KPT];
+            tile_cols(it, col);
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) acc[u][mt] = f32x4{bia[mt][0], bia[mt][1], bia[mt][2], bia[mt][3]};
-            // B fragments: three swizzled column addresses per token tile (dx = -1, 0, +1; key =
-            // cell & 7), each serving the three rows of the window at -1 KiB, 0, +1 KiB; chunk
-            // 4*ks + l4, i.e. the second half of the cell is the first with address bit 6 flipped
-            uint32_t col[2][3][KPT];            // row above the window (p >= 8: never below the image)
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    const uint32_t p = static_cast<uint32_t>(pc[u] + d - 1 - PCOLS);
-                    // (the mask tells the compiler the offset is small and non-negative, which is
-                    // what lets it put the row displacement into the ds_read offset field)
-                    const uint32_t o = (p * CELLB + ((l4 ^ (p & 7)) << 4)) & 0xffffu;
-#pragma unroll
-                    for (int ks = 0; ks < KPT; ++ks) col[u][d][ks] = o ^ (ks << 6);
-                }
-            auto fetch = [&](int tap, bf16x8 (&xf)[2][KPT]) {
-                const int dy = tap / 3, d = tap % 3;
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int ks = 0; ks < KPT; ++ks)
-                        xf[u][ks] = *reinterpret_cast<const bf16x8 *>(&smem[col[u][d][ks] + dy * PCOLS * CELLB]);   // img = smem + 0
-            };
-            // one tap ahead: the reads of tap+1 are issued before the MFMAs of tap, and the
-            // scheduling barrier keeps the compiler from hoisting all 36 reads (144 VGPRs) to the top
-            bf16x8 xa[2][KPT], xb[2][KPT];
-            fetch(0, xa);
+            for (int mt = 0; mt < 2; ++mt) acc[mt] = f32x4{bia[mt][0], bia[mt][1], bia[mt][2], bia[mt][3]};
+            Epi e;
+            if (with_epi) epi_begin(it - 1, e);
+            bf16x8 xa[KPT], xb[KPT];
+            fetch(col, 0, xa);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
-                bf16x8 (&cur)[2][KPT] = (tap & 1) ? xb : xa;
-                bf16x8 (&nxt)[2][KPT] = (tap & 1) ? xa : xb;
-                if (tap + 1 < 9) fetch(tap + 1, nxt);
-#pragma unroll
-                for (int ks = 0; ks < KPT; ++ks) {
-                    const int s = tap * KPT + ks;
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[0][s], cur[0][ks], acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[1][s], cur[0][ks], acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[0][s], cur[1][ks], acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[1][s], cur[1][ks], acc[1][1], 0, 0, 0);
-                }
+                bf16x8 (&cur)[KPT] = (tap & 1) ? xb : xa;
+                bf16x8 (&nxt)[KPT] = (tap & 1) ? xa : xb;
+                if (tap + 1 < 9) fetch(col, tap + 1, nxt);
                 __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < KPT; ++ks)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const int s = tap * KPT + ks;
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[mt][s], cur[ks], acc[mt], 0, 0, 0);
+                        if (with_epi) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            constexpr int PER_SLOT = 36 / (18 * KPT);          // 1 (C_in 64) or 2 (C_in 32)
+                            const int slot = (tap * KPT + ks) * 2 + mt;
+#pragma unroll
+                            for (int j = 0; j < PER_SLOT; ++j) epi_step(slot * PER_SLOT + j, pacc, e);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
             }
-            // epilogue on the accumulators: this lane holds channels 8*(4*mh+l4) .. +7 of token
-            // (lane & 15): bias, SiLU, residual, and the vector goes to the output tile in LDS
+            if (with_epi) epi_end(e);
+        };
+        if (!(dbg & 1)) {
+            f32x4 acc_a[2], acc_b[2];
+            block(0, acc_a, false, acc_b);
+#pragma unroll 1
+            for (int it = 1; it < 6; it += 2) {
+                // two tiles per trip so that the accumulator sets alternate without copies
+                block(it, acc_b, true, acc_a);
+                if (it + 1 < 6) block(it + 1, acc_a, true, acc_b);
+            }
+            {   // drain: the last tile's epilogue on its own
+                Epi e;
+                epi_begin(5, e);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (row[u] >= TROWS || (dbg & 2)) continue;
-                const int smp = row[u] / CELLS, cell = row[u] - smp * CELLS;
-                V8 *slot = reinterpret_cast<V8 *>(outt + smp * OSB + cell * 128 + (((mh * 4 + l4) ^ (cell & 7)) << 4));
-                V8 rr;
-                if (RESID) rr = *slot;
-                V8 o;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x2 v = silu2(f32x2{acc[u][q >> 1][2 * (q & 1)], acc[u][q >> 1][2 * (q & 1) + 1]});
-                    if (RESID) v += unpack2(rr.w[q]);
-                    o.w[q] = pack2(v.x, v.y);
-                }
-                *slot = o;
+                for (int step = 0; step < 36; ++step) epi_step(step, acc_b, e);
+                epi_end(e);
             }
         }
         // the staged tile has landed; every wave is done with img and has written its outputs
@@ -423,7 +450,7 @@ int launch(const void *x, const void *w, const void *bias, const void *gamma, co
            float eps, hipStream_t s)
 {
     constexpr size_t smem = static_cast<size_t>(TS) * PCELLS * CELLB + 2 * static_cast<size_t>(TS) * CELLS * CIN * 2 +
-                            (RESID ? 0 : static_cast<size_t>(TS) * CELLS * COUT * 2) + 2 * CIN * sizeof(float);
+                            (RESID ? 0 : static_cast<size_t>(TS) * CELLS * COUT * 2) + 2 * CIN * sizeof(float) + 512;
     static bool attr_set = false;
     auto kern = k_conv_block<CIN, NORM, RESID>;
     if (!attr_set) {
