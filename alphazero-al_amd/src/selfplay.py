@@ -11,11 +11,23 @@ loop and keeps finished games in the batch until the slowest one ends.  Here a p
 so every slot plays a live position on every ply.  Same search semantics as
 BatchedMCTS.batch_playout; the schedule of temperatures follows game.py:55-63.
 
-This file is what bench.py times.  Recording full training trajectories
-(game.py:131-157 tuples) on the device is the next step.
+This file is what bench.py times.
+
+With `record=True` the driver also keeps, in HBM, what the reference's harness keeps per ply
+(game.py:97-108: position, visit distribution, root WDL, legal-move mask, side to move), moves
+every finished game's rows into a store of finished games with one scatter per ply (no host
+synchronisation), and `drain()` turns that store into the reference's exact `play_data`
+tuples (game.py:110-157: winner_z, steps_to_end, aux targets, td_steps future root WDL and the
+terminal tuple) - SURVEY section 8f row f1.  Two switches exist for parity tests against the
+reference harness, which carries finished games to the end and samples with numpy:
+`refill=False` leaves a finished slot dead instead of starting a new game in it, and
+`sampler="reference"` draws the moves on the host with the reference's procedure and numpy's
+global generator (player.py:348-371).  Not restated: the noise-epsilon decay over the plies
+of a game (game.py:88-92, `noise_steps`; off in the server defaults).
 """
 import ctypes as C
 
+import numpy as np
 import torch
 
 from src import fused as F
@@ -26,7 +38,8 @@ class DeviceSelfPlay:
     def __init__(self, net, n_games, n_playout=200, vl_batch=4, c_init=1.4, c_base=None, alpha=0.3,
                  noise_epsilon=0.25, fpu_reduction=0.2, use_symmetry=True, mlh_slope=0.1, mlh_cap=0.2,
                  value_decay=1.0, temperature=1.0, temp_decay_moves=20, temp_endgame=0.0, seed=0,
-                 reserve_slots=None):
+                 reserve_slots=None, record=False, td_steps=0, refill=True, sampler="device",
+                 max_finished_games=None):
         self.B = int(n_games)
         self.n_playout = int(n_playout)
         self.vl_batch = int(vl_batch)
@@ -57,6 +70,28 @@ class DeviceSelfPlay:
         self.totals = torch.zeros(5, dtype=torch.int64, **z)
         if reserve_slots:
             F.check(F.lib().az_mcts_reserve(self.h, int(reserve_slots)))
+        assert sampler in ("device", "reference")
+        self.sampler, self.refill, self.record, self.td_steps = sampler, bool(refill), bool(record), int(td_steps)
+        self.dead = torch.zeros(self.B, dtype=torch.bool, **z)        # refill=False: slots whose game is over
+        self.ar = torch.arange(self.B, **z)
+        if self.record:
+            A = self.search.action_size
+            self.stats = torch.zeros((self.B, 6 + 8 * A), dtype=torch.float32, **z)
+            T = self.MAX_PLIES + 2                                    # plies + end state + one scratch column
+            self.G = int(max_finished_games or max(4 * self.B, 1024))
+            def rows(n):
+                return dict(bb1=torch.zeros((n, T), dtype=torch.int64, **z), bb2=torch.zeros((n, T), dtype=torch.int64, **z),
+                            turn=torch.zeros((n, T), dtype=torch.int8, **z), prob=torch.zeros((n, T, A), dtype=torch.float32, **z),
+                            wdl=torch.zeros((n, T, 3), dtype=torch.float32, **z), mask=torch.zeros((n, T, A), dtype=torch.bool, **z))
+            self.rec = rows(self.B)                                   # the games in progress
+            self.fin = rows(self.G + 1)                               # finished games (+ one scratch row)
+            self.fin_len = torch.zeros(self.G + 1, dtype=torch.int32, **z)
+            self.fin_winner = torch.zeros(self.G + 1, dtype=torch.int32, **z)
+            self.fin_slot = torch.zeros(self.G + 1, dtype=torch.int32, **z)
+            self.n_finished = torch.zeros((), dtype=torch.int64, **z)
+            self.n_dropped = torch.zeros((), dtype=torch.int64, **z)
+
+    MAX_PLIES = 42
 
     def _pick_actions(self):
         """Visit counts -> move: proportional to N^(1/T) while T > 0, arg-max otherwise
@@ -77,6 +112,65 @@ class DeviceSelfPlay:
         sampled = torch.multinomial(safe, 1, generator=self.gen).squeeze(1)
         self.actions.copy_(torch.where(hot, sampled, greedy).to(torch.int32))
 
+    def _pick_actions_reference(self):
+        """player.py:348-371 verbatim on the host (numpy's global generator): for parity runs."""
+        visits = self.counts.cpu().numpy().astype(np.int64)
+        ply = self.ply.cpu().numpy()
+        dead = self.dead.cpu().numpy()
+        acts = np.zeros(self.B, dtype=np.int32)
+        for i in range(self.B):
+            visit = visits[i]
+            valid = visit > 0
+            if dead[i] or not valid.any():
+                acts[i] = -1 if dead[i] else 0
+                continue
+            if self.temp_decay_moves <= 0:
+                temp = self.temperature
+            else:
+                temp = self.temperature if ply[i] < self.temp_decay_moves else self.temp_endgame
+            if temp <= 1e-6:
+                acts[i] = int(np.argmax(visit))
+            else:
+                log_visits = np.log(visit[valid])
+                x = log_visits / temp
+                pr = np.exp(x - np.max(x))
+                acts[i] = int(np.random.choice(np.where(valid)[0], p=pr / np.sum(pr)))
+        self.actions.copy_(torch.from_numpy(acts).to(self.device))
+
+    def _record_position(self):
+        """What game.py:97-108 appends before the move is played."""
+        idx = torch.where(self.dead, torch.full_like(self.ply, self.MAX_PLIES + 1), self.ply).long()
+        r = self.rec
+        r["bb1"][self.ar, idx] = self.bb_p1
+        r["bb2"][self.ar, idx] = self.bb_p2
+        r["turn"][self.ar, idx] = self.turn.to(torch.int8)
+        visits = self.counts.to(torch.float64)                      # player.py:356: int / int in double, stored as f32
+        tot = visits.sum(1, keepdim=True)
+        r["prob"][self.ar, idx] = torch.where(tot > 0, visits / tot.clamp_min(1), torch.zeros_like(visits)).to(torch.float32)
+        r["wdl"][self.ar, idx] = self.stats[:, 3:6]
+        occ = (self.bb_p1 | self.bb_p2).unsqueeze(1)
+        top = torch.arange(self.search.action_size, device=self.device, dtype=torch.int64) * 7 + 5
+        r["mask"][self.ar, idx] = ((occ >> top) & 1) == 0
+
+    def _record_finished(self, fin):
+        """End state of the games that just finished, then their rows move to the finished store."""
+        idx = torch.where(fin, self.ply, torch.full_like(self.ply, self.MAX_PLIES + 1)).long()   # ply already counts the last move
+        r = self.rec
+        r["bb1"][self.ar, idx] = self.bb_p1
+        r["bb2"][self.ar, idx] = self.bb_p2
+        r["turn"][self.ar, idx] = self.turn.to(torch.int8)
+        rank = torch.cumsum(fin.to(torch.int64), 0) - 1
+        dst = self.n_finished + rank
+        keep = fin & (dst < self.G)
+        dst = torch.where(keep, dst, torch.full_like(dst, self.G))
+        for k, v in self.fin.items():
+            v.index_copy_(0, dst, r[k])
+        self.fin_len.index_copy_(0, dst, self.ply)
+        self.fin_winner.index_copy_(0, dst, self.winner)
+        self.fin_slot.index_copy_(0, dst, self.ar.to(torch.int32))
+        self.n_finished += keep.sum()
+        self.n_dropped += (fin & ~keep).sum()
+
     def step(self):
         """One ply in every game."""
         L = F.lib()
@@ -85,17 +179,73 @@ class DeviceSelfPlay:
                                         self.turn.data_ptr(), s))
         self.fused.search(self.n_playout, self.vl_batch)
         F.check(L.az_mcts_dev_counts(self.h, self.counts.data_ptr(), s))
-        self._pick_actions()
+        if self.sampler == "reference":
+            self._pick_actions_reference()
+        else:
+            self._pick_actions()
+            if not self.refill:
+                self.actions.masked_fill_(self.dead, -1)
+        if self.record:
+            F.check(L.az_mcts_dev_root_stats(self.h, self.stats.data_ptr(), s))
+            self._record_position()
         F.check(L.az_mcts_dev_prune_roots(self.h, self.actions.data_ptr(), s))
+        # with recording the end state has to survive the step: finished boards are reset below
+        kernel_refill = 1 if (self.refill and not self.record) else 0
         F.check(L.az_c4_dev_step(self.bb_p1.data_ptr(), self.bb_p2.data_ptr(), self.turn.data_ptr(),
                                  self.actions.data_ptr(), self.done.data_ptr(), self.winner.data_ptr(),
-                                 self.B, 1, s))
+                                 self.B, kernel_refill, s))
         F.check(L.az_mcts_dev_reset_masked(self.h, self.done.data_ptr(), s))
+        fin_b = self.done.bool()
         fin = self.done.to(torch.int64)
-        self.ply = torch.where(self.done.bool(), torch.zeros_like(self.ply), self.ply + 1)
+        self.ply = torch.where(self.dead, self.ply, self.ply + 1)
+        if self.record:
+            self._record_finished(fin_b)
+        if self.refill:
+            if not kernel_refill:
+                self.bb_p1.masked_fill_(fin_b, 0)
+                self.bb_p2.masked_fill_(fin_b, 0)
+                self.turn.masked_fill_(fin_b, 1)
+            self.ply = torch.where(fin_b, torch.zeros_like(self.ply), self.ply)
+        else:
+            self.dead |= fin_b
         self.totals += torch.stack([torch.tensor(self.B, device=self.device), fin.sum(),
                                     (fin * (self.winner == 1)).sum(), (fin * (self.winner == -1)).sum(),
                                     (fin * (self.winner == 0)).sum()])
+
+    def drain(self):
+        """Finished games since the last call, as the reference's `batch_self_play` returns them:
+        a list of (winner, play_data) with play_data the tuple of per-ply tuples of
+        game.py:131-157 (+ the terminal tuple), plus the slot each game was played in.
+        Synchronises; the store is emptied."""
+        assert self.record
+        n = int(self.n_finished.item())
+        host = {k: v[:n].cpu().numpy() for k, v in self.fin.items()}
+        lens = self.fin_len[:n].cpu().numpy()
+        winners = self.fin_winner[:n].cpu().numpy()
+        slots = self.fin_slot[:n].cpu().numpy()
+        self.n_finished.zero_()
+        games = []
+        zero_wdl = np.zeros(3, dtype=np.float32)
+        k = self.td_steps
+        for g in range(n):
+            T = int(lens[g])
+            winner = int(winners[g])
+            states = planes_from_bitboards(host["bb1"][g, :T + 1], host["bb2"][g, :T + 1], host["turn"][g, :T + 1])
+            winner_z = np.full(T, winner, dtype=np.int32)
+            steps_to_end = np.arange(T, 0, -1, dtype=np.int32)
+            aux = steps_to_end                                       # game.py:17-23, Connect4: moves left
+            probs, wdls, masks = host["prob"][g], host["wdl"][g], host["mask"][g]
+            cols = [list(states[:T]), [probs[t] for t in range(T)], list(winner_z), list(steps_to_end), list(aux),
+                    [wdls[t] for t in range(T)], [masks[t] for t in range(T)]]
+            if k > 0:
+                cols.append([wdls[t + k] if t + k < T else zero_wdl for t in range(T)])
+            play = list(zip(*cols))
+            terminal = [states[T], np.zeros_like(probs[0]), winner, 0, 0, zero_wdl, np.ones_like(masks[0])]
+            if k > 0:
+                terminal.append(zero_wdl)
+            play.append(tuple(terminal))
+            games.append((winner, tuple(play), int(slots[g])))
+        return games
 
     def read_totals(self):
         t = self.totals.cpu().tolist()          # synchronises
@@ -103,3 +253,23 @@ class DeviceSelfPlay:
 
     def engine_counters(self):
         return F.counters(self.h)
+
+
+def planes_from_bitboards(bb_p1, bb_p2, turn):
+    """(n,) bitboards (bit 7*col + height) and side to move -> the (n, 3, 6, 7) int8 planes of
+    `Env.current_state()` (env_common.h:93-119): stones of the side to move, stones of the
+    opponent, the turn sign everywhere; row 0 is the top of the board."""
+    bb_p1 = np.asarray(bb_p1).astype(np.uint64)
+    bb_p2 = np.asarray(bb_p2).astype(np.uint64)
+    turn = np.asarray(turn).astype(np.int8)
+    n = bb_p1.shape[0]
+    own = np.where(turn > 0, bb_p1, bb_p2)
+    opp = np.where(turn > 0, bb_p2, bb_p1)
+    out = np.zeros((n, 3, 6, 7), dtype=np.int8)
+    for c in range(7):
+        for h in range(6):
+            bit = np.uint64(7 * c + h)
+            out[:, 0, 5 - h, c] = (own >> bit) & np.uint64(1)
+            out[:, 1, 5 - h, c] = (opp >> bit) & np.uint64(1)
+    out[:, 2] = turn[:, None, None]
+    return out

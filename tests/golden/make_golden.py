@@ -256,6 +256,30 @@ def gen_g8():
     save("g8_selfplay", **out)
 
 
+# ------------------------------------------------------------------ G10 self-play harness without native randomness
+def gen_g10():
+    """The same harness as G8 with Dirichlet noise and symmetry off (the epsilon prior scaling
+    stays on): every random draw is numpy's, so a device-resident self-play driver that
+    samples moves with the reference's numpy procedure must reproduce these tuples bit for
+    bit."""
+    from src.game import Game
+    from src.player import AlphaZeroPlayer
+    pv = S.HashPV()
+    np.random.seed(5)
+    player = AlphaZeroPlayer(pv, n_envs=16, c_init=1.4, c_base=240, n_playout=48, alpha=0.0,
+                             is_selfplay=1, noise_epsilon=0.25, fpu_reduction=0.2,
+                             use_symmetry=False, mlh_slope=0.1, mlh_cap=0.2, vl_batch=4)
+    player.mcts.seed(3)
+    data = Game(Env()).batch_self_play(player, 16, temperature=1.0, temp_decay_moves=8, temp_endgame=0,
+                                       td_steps=2)
+    out = {}
+    for i, (winner, play) in enumerate(data):
+        out[f"g{i}_winner"] = np.array([winner], np.int32)
+        for j, nm in enumerate(("state", "prob", "z", "steps", "aux", "root_wdl", "mask", "fut")):
+            out[f"g{i}_{nm}"] = np.array([np.asarray(tup[j]) for tup in play])
+    save("g10_selfplay_numpy_rng", **out)
+
+
 # ------------------------------------------------------------------ Othello (config 4)
 def gen_othello():
     from src.env_cpp.othello import Env as OEnv
@@ -285,8 +309,8 @@ def gen_othello():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rng", "g1", "g2", "search", "g6", "rollout", "g7", "g8", "othello"]
+    which = sys.argv[1:] or ["rng", "g1", "g2", "search", "g6", "rollout", "g7", "g8", "g10", "othello"]
     fns = dict(rng=gen_rng, g1=gen_g1, g2=gen_g2, search=gen_search, g6=gen_g6,
-               rollout=gen_rollout, g7=gen_g7, g8=gen_g8, othello=gen_othello)
+               rollout=gen_rollout, g7=gen_g7, g8=gen_g8, g10=gen_g10, othello=gen_othello)
     for w in which:
         fns[w]()

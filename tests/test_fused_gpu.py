@@ -432,6 +432,72 @@ def test_device_selfplay_driver(env):
     assert 1 < used.value <= env["F"].lib().az_mcts_capacity(sp.h)
 
 
+def test_device_selfplay_trajectories_equal_reference_harness_g10(env):
+    """the device driver's recorded trajectories, drained into play_data
+    tuples, against the reference's own Game.batch_self_play + AlphaZeroPlayer output (fixture
+    G10: no Dirichlet noise, no symmetry, so every random draw is numpy's and the driver's
+    `sampler="reference"` replays it).  Bit-exact: states, visit distributions, root WDL,
+    masks, targets, td-step WDL and the terminal tuples of all 16 games."""
+    g = load("g10_selfplay_numpy_rng")
+    net = env["H"].HashEvaluator("cuda")
+    np.random.seed(5)
+    sp = env["SP"].DeviceSelfPlay(net, 16, n_playout=48, vl_batch=4, c_init=1.4, c_base=240, alpha=0.0,
+                                  noise_epsilon=0.25, fpu_reduction=0.2, use_symmetry=False, mlh_slope=0.1,
+                                  mlh_cap=0.2, temperature=1.0, temp_decay_moves=8, temp_endgame=0, seed=3,
+                                  record=True, td_steps=2, refill=False, sampler="reference")
+    for _ in range(43):
+        sp.step()
+        if bool(sp.dead.all()):
+            break
+    assert bool(sp.dead.all())
+    games = sorted(sp.drain(), key=lambda t: t[2])
+    assert [t[2] for t in games] == list(range(16))
+    for i, (winner, play, _slot) in enumerate(games):
+        assert winner == int(g[f"g{i}_winner"][0]), i
+        for j, nm in enumerate(("state", "prob", "z", "steps", "aux", "root_wdl", "mask", "fut")):
+            got = np.array([np.asarray(t[j]) for t in play])
+            ref = g[f"g{i}_{nm}"]
+            assert got.shape == ref.shape and got.dtype == ref.dtype, (i, nm, got.shape, ref.shape, got.dtype, ref.dtype)
+            if ref.dtype.kind == "f":
+                assert np.array_equal(bits(got), bits(ref)), (i, nm)
+            else:
+                assert np.array_equal(got, ref), (i, nm)
+
+
+def test_device_selfplay_recording_with_refill(env):
+    """Recording in the production mode (device sampling, finished slots refilled at once):
+    structural invariants of every drained game."""
+    net = env["H"].HashEvaluator("cuda")
+    sp = env["SP"].DeviceSelfPlay(net, 128, n_playout=24, vl_batch=4, seed=2, temp_decay_moves=6, record=True, td_steps=3)
+    for _ in range(70):
+        sp.step()
+    games = sp.drain()
+    tot = sp.read_totals()
+    assert len(games) == tot["games"] > 128 and int(sp.n_dropped.item()) == 0
+    assert sum(w == 1 for w, _, _ in games) == tot["p1_wins"] and sum(w == 0 for w, _, _ in games) == tot["draws"]
+    for winner, play, slot in games:
+        T = len(play) - 1
+        assert 7 <= T <= 42 and 0 <= slot < 128
+        for t, tup in enumerate(play[:-1]):
+            state, prob, z, steps, aux, wdl, mask, fut = tup
+            assert state.dtype == np.int8 and state.shape == (3, 6, 7) and prob.dtype == np.float32
+            assert int(state[:2].sum()) == t and (state[2] == (1 if t % 2 == 0 else -1)).all()
+            assert abs(float(prob.sum()) - 1.0) < 1e-6 and (prob[~mask] == 0).all()
+            assert (mask == (state[:2, 0].sum(0) == 0)).all()
+            assert z == winner and steps == T - t and aux == T - t
+            assert abs(float(wdl.sum()) - 1.0) < 1e-4
+            ref_fut = play[t + 3][5] if t + 3 < T else np.zeros(3, np.float32)
+            assert np.array_equal(fut, ref_fut)
+        end = play[-1]
+        assert int(end[0][:2].sum()) == T and end[2] == winner and end[3] == 0 and (end[1] == 0).all() and end[6].all()
+        # absolute board of the end state: plane 0 = side to move, plane 1 = the player who just moved
+        to_move = 1 if T % 2 == 0 else -1
+        board = end[0][0].astype(np.int8) * to_move - end[0][1].astype(np.int8) * to_move
+        assert S.np_winner(board) == winner and S.np_done(board)
+    # draining empties the store
+    assert sp.drain() == []
+
+
 def test_fused_path_othello_bit_exact_vs_oracle(env):
     """Config-4 game through the device-resident loop: 65 actions, passes, score utility."""
     rng = np.random.default_rng(44)
