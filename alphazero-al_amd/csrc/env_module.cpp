@@ -437,6 +437,268 @@ void register_othello(py::module_ &m)
         .def_property_readonly("bitboards", [](const OtEnv &e) { return py::make_tuple(e.bb[0], e.bb[1]); });
 }
 
+
+// ============================================================================ Gomoku
+// Host-side position object only: the reference binds no Gomoku search (mcts_bindings.cpp:393-394
+// registers Connect4 and Othello), so this exists for the surface `src.env_cpp.gomoku.Env`
+// (env_gomoku.h:67-170 over Gomoku.h).  Square board of run-time size, n stones in a row win.
+struct GmEnv {
+    int n = 15, need = 5;
+    std::vector<int8_t> cells;
+    int turn = 1, stones = 0, last = -1, winner = 0;
+    bool over = false;
+
+    GmEnv(int board_size = 15, int n_in_row = 5) { configure(board_size, n_in_row); }
+
+    void configure(int board_size, int n_in_row)
+    {
+        // messages as Gomoku.h:214-222
+        if (board_size <= 0) throw std::runtime_error("board_size must be positive");
+        if (n_in_row <= 1) throw std::runtime_error("n_in_row must be >= 2");
+        if (n_in_row > board_size) throw std::runtime_error("n_in_row must be <= board size");
+        n = board_size;
+        need = n_in_row;
+        cells.assign(static_cast<size_t>(n) * n, 0);
+        clear();
+    }
+    void clear()
+    {
+        std::fill(cells.begin(), cells.end(), 0);
+        turn = 1; stones = 0; last = -1; winner = 0; over = false;
+    }
+    int area() const { return n * n; }
+    bool inside(int r, int c) const { return r >= 0 && r < n && c >= 0 && c < n; }
+    // length of the run of `who` through (r, c) along (dr, dc), the cell itself included
+    int run(int r, int c, int dr, int dc, int who) const
+    {
+        int len = 1;
+        for (int s = -1; s <= 1; s += 2)
+            for (int k = 1; inside(r + s * k * dr, c + s * k * dc) && cells[(r + s * k * dr) * n + c + s * k * dc] == who; ++k) ++len;
+        return len;
+    }
+    bool wins_through(int a, int who) const
+    {
+        const int r = a / n, c = a % n;
+        return run(r, c, 1, 0, who) >= need || run(r, c, 0, 1, who) >= need || run(r, c, 1, 1, who) >= need ||
+               run(r, c, 1, -1, who) >= need;
+    }
+    void play(int a)                                   // Gomoku.h:73-99
+    {
+        if (over) throw std::runtime_error("game is already finished");
+        if (a < 0 || a >= area()) throw std::runtime_error("action out of range");
+        if (cells[a] != 0) throw std::runtime_error("cell is already occupied");
+        cells[a] = static_cast<int8_t>(turn);
+        ++stones;
+        last = a;
+        if (wins_through(a, turn)) { winner = turn; over = true; }
+        else if (stones == area()) { winner = 0; over = true; }
+        turn = -turn;
+    }
+    void set_turn(int t)
+    {
+        if (t != 1 && t != -1) throw std::runtime_error("turn must be 1 or -1");
+        turn = t;
+    }
+    // rebuild everything from the grid: side to move from the stone counts, first winning
+    // stone in scan order decides the winner (Gomoku.h:166-209)
+    void rescan()
+    {
+        int p1 = 0, p2 = 0;
+        last = -1;
+        for (int i = 0; i < area(); ++i) {
+            if (cells[i] == 1) { ++p1; last = i; }
+            else if (cells[i] == -1) { ++p2; last = i; }
+            else if (cells[i] != 0) throw std::runtime_error("board values must be -1, 0, or 1");
+        }
+        stones = p1 + p2;
+        turn = p1 == p2 ? 1 : (p1 == p2 + 1 ? -1 : (stones % 2 == 0 ? 1 : -1));
+        winner = 0;
+        for (int i = 0; i < area() && winner == 0; ++i)
+            if (cells[i] != 0 && wins_through(i, cells[i])) winner = cells[i];
+        over = winner != 0 || stones == area();
+    }
+    // the dihedral group of the square, numbered as Gomoku.h:270-289
+    void map(int sym, int r, int c, int &nr, int &nc) const
+    {
+        const int m = n - 1;
+        switch (sym) {
+        case 0: nr = r; nc = c; break;
+        case 1: nr = c; nc = m - r; break;
+        case 2: nr = m - r; nc = m - c; break;
+        case 3: nr = m - c; nc = r; break;
+        case 4: nr = r; nc = m - c; break;
+        case 5: nr = m - r; nc = c; break;
+        case 6: nr = c; nc = r; break;
+        case 7: nr = m - c; nc = m - r; break;
+        default: throw std::runtime_error("invalid symmetry id");
+        }
+    }
+    int map_action(int sym, int a) const
+    {
+        int nr, nc;
+        map(sym, a / n, a % n, nr, nc);
+        return nr * n + nc;
+    }
+    void transform(int sym)
+    {
+        if (sym < 0 || sym >= 8) throw std::runtime_error("invalid symmetry id");
+        if (sym == 0) return;
+        std::vector<int8_t> out(cells.size(), 0);
+        for (int a = 0; a < area(); ++a) out[map_action(sym, a)] = cells[a];
+        cells.swap(out);
+        if (last >= 0) last = map_action(sym, last);
+    }
+};
+
+py::array_t<float> gm_grid(const GmEnv &e)
+{
+    py::array_t<float> arr({e.n, e.n});
+    auto b = arr.mutable_unchecked<2>();
+    for (int r = 0; r < e.n; ++r)
+        for (int c = 0; c < e.n; ++c) b(r, c) = static_cast<float>(e.cells[r * e.n + c]);
+    return arr;
+}
+
+void gm_set_grid(GmEnv &e, py::array_t<float, py::array::c_style | py::array::forcecast> arr)
+{
+    auto b = arr.unchecked<2>();
+    if (b.shape(0) != e.n || b.shape(1) != e.n) throw std::runtime_error("board shape does not match environment dimensions");
+    for (int r = 0; r < e.n; ++r)
+        for (int c = 0; c < e.n; ++c) e.cells[r * e.n + c] = static_cast<int8_t>(b(r, c));
+    e.rescan();
+}
+
+GmEnv gm_from_grid(py::array_t<float, py::array::c_style | py::array::forcecast> arr, int n_in_row)
+{
+    auto b = arr.unchecked<2>();
+    if (b.shape(0) != b.shape(1)) throw std::runtime_error("board must be square");
+    GmEnv e(static_cast<int>(b.shape(0)), n_in_row);
+    gm_set_grid(e, arr);
+    return e;
+}
+
+void register_gomoku(py::module_ &m)
+{
+    auto sub = m.def_submodule("gomoku", "Gomoku-like environment with configurable board and win length");
+    py::class_<GmEnv>(sub, "Env")
+        .def(py::init<int, int>(), py::arg("board_size") = 15, py::arg("n_in_row") = 5)
+        .def(py::init(&gm_from_grid), py::arg("board"), py::arg("n_in_row") = 5)
+        .def("reset", &GmEnv::clear)
+        .def("copy", [](const GmEnv &e) { return GmEnv(e); })
+        .def("step", &GmEnv::play, py::arg("action"))
+        .def("winPlayer", [](const GmEnv &e) { return e.winner; })
+        .def("check_winner", [](const GmEnv &e) { return e.winner; })
+        .def("check_full", [](const GmEnv &e) { return e.stones == e.area(); })
+        .def_property("turn", [](const GmEnv &e) { return e.turn; }, &GmEnv::set_turn)
+        .def_property_readonly_static("NUM_SYMMETRIES", [](py::object) { return 8; })
+        .def(
+            "apply_symmetry",
+            [](GmEnv &e, int sym_id, bool inplace) {
+                if (inplace) { e.transform(sym_id); return e; }
+                GmEnv c(e);
+                c.transform(sym_id);
+                return c;
+            },
+            py::arg("sym_id"), py::arg("inplace") = false)
+        .def("random_symmetry",
+             [](const GmEnv &e) {
+                 static thread_local std::mt19937 rng(std::random_device{}());
+                 const int sym = std::uniform_int_distribution<int>(0, 7)(rng);
+                 GmEnv c(e);
+                 c.transform(sym);
+                 return py::make_tuple(c, sym);
+             })
+        .def_property("board", &gm_grid, &gm_set_grid)
+        .def_property_readonly("board_size", [](const GmEnv &e) { return e.n; })
+        .def_property_readonly("rows", [](const GmEnv &e) { return e.n; })
+        .def_property_readonly("cols", [](const GmEnv &e) { return e.n; })
+        .def_property_readonly("n_in_row", [](const GmEnv &e) { return e.need; })
+        .def_property_readonly("action_size", &GmEnv::area)
+        .def_property_readonly("num_symmetries", [](const GmEnv &) { return 8; })
+        .def("set_params", &GmEnv::configure, py::arg("board_size"), py::arg("n_in_row"))
+        .def("done", [](const GmEnv &e) { return e.over; })
+        .def(
+            "coord_to_action",
+            [](const GmEnv &e, int row, int col) {
+                if (!e.inside(row, col)) throw std::runtime_error("row/col out of range");
+                return row * e.n + col;
+            },
+            py::arg("row"), py::arg("col"))
+        .def(
+            "step_xy",
+            [](GmEnv &e, int row, int col) {
+                if (!e.inside(row, col)) throw std::runtime_error("row/col out of range");
+                e.play(row * e.n + col);
+            },
+            py::arg("row"), py::arg("col"))
+        .def(
+            "action_to_coord",
+            [](const GmEnv &e, int action) {
+                if (action < 0 || action >= e.area()) throw std::runtime_error("action out of range");
+                return py::make_tuple(action / e.n, action % e.n);
+            },
+            py::arg("action"))
+        .def("valid_move",
+             [](const GmEnv &e) {
+                 py::list l;
+                 for (int a = 0; a < e.area(); ++a)
+                     if (e.cells[a] == 0) l.append(a);
+                 return l;
+             })
+        .def("valid_mask",
+             [](const GmEnv &e) {
+                 py::list l;
+                 for (int a = 0; a < e.area(); ++a) l.append(e.cells[a] == 0);
+                 return l;
+             })
+        .def("current_state",
+             [](const GmEnv &e) {                         // env_common.h:93-119
+                 py::array_t<float> st({1, 3, e.n, e.n});
+                 auto b = st.mutable_unchecked<4>();
+                 for (int r = 0; r < e.n; ++r)
+                     for (int c = 0; c < e.n; ++c) {
+                         const int v = e.cells[r * e.n + c];
+                         b(0, 0, r, c) = v == e.turn ? 1.0f : 0.0f;
+                         b(0, 1, r, c) = v == -e.turn ? 1.0f : 0.0f;
+                         b(0, 2, r, c) = static_cast<float>(e.turn);
+                     }
+                 return st;
+             })
+        .def(
+            "inverse_symmetry_action",
+            [](const GmEnv &e, int sym_id, int action) {  // (sic) the forward map, as Gomoku.h:128-141
+                if (action < 0 || action >= e.area()) throw std::runtime_error("action out of range");
+                if (sym_id < 0 || sym_id >= 8) throw std::runtime_error("invalid symmetry id");
+                return e.map_action(sym_id, action);
+            },
+            py::arg("sym_id"), py::arg("action"))
+        .def("show",
+             [](const GmEnv &e) {
+                 std::ostringstream os;
+                 os << "==============================\n    ";
+                 for (int c = 0; c < e.n; ++c) os << c % 10 << ' ';
+                 os << '\n';
+                 for (int r = 0; r < e.n; ++r) {
+                     os << (r < 10 ? " " : "") << r << "  ";
+                     for (int c = 0; c < e.n; ++c) {
+                         const int v = e.cells[r * e.n + c];
+                         os << (v == 0 ? '.' : (v == 1 ? 'X' : 'O')) << ' ';
+                     }
+                     os << '\n';
+                 }
+                 os << "==============================";
+                 py::print(os.str());
+             })
+        .def(py::pickle(
+            [](const GmEnv &e) { return py::make_tuple(gm_grid(e), e.turn, e.need); },
+            [](py::tuple t) {
+                if (t.size() != 3) throw std::runtime_error("Invalid pickle state");
+                GmEnv e = gm_from_grid(t[0].cast<py::array_t<float>>(), t[2].cast<int>());
+                e.set_turn(t[1].cast<int>());
+                return e;
+            }));
+}
+
 }  // namespace
 
 PYBIND11_MODULE(env_cpp, m)
@@ -444,4 +706,5 @@ PYBIND11_MODULE(env_cpp, m)
     m.doc() = "Game environments (host-side position objects; drop-in for the reference's env_cpp)";
     register_connect4(m);
     register_othello(m);
+    register_gomoku(m);
 }

@@ -280,6 +280,42 @@ def gen_g10():
     save("g10_selfplay_numpy_rng", **out)
 
 
+# ------------------------------------------------------------------ Gomoku Env (surface only: no search binding in the reference)
+def gen_gomoku():
+    from src.env_cpp.gomoku import Env as GEnv
+    rng = np.random.default_rng(77)
+    out = {}
+    for gi, (size, need) in enumerate(((15, 5), (9, 5), (7, 4), (5, 3), (6, 6), (3, 3))):
+        for rep in range(3):
+            e = GEnv(size, need)
+            acts, boards, turns, winners, dones, states = [], [], [], [], [], []
+            while not e.done():
+                a = int(rng.choice(e.valid_move()))
+                e.step(a)
+                acts.append(a); boards.append(np.asarray(e.board).astype(np.int8)); turns.append(e.turn)
+                winners.append(e.winPlayer()); dones.append(e.done()); states.append(e.current_state()[0].astype(np.int8))
+            k = f"s{gi}r{rep}"
+            out[k + "_cfg"] = np.array([size, need], np.int32)
+            out[k + "_actions"] = np.array(acts, np.int32)
+            out[k + "_boards"] = np.array(boards)
+            out[k + "_turns"] = np.array(turns, np.int32)
+            out[k + "_winners"] = np.array(winners, np.int32)
+            out[k + "_dones"] = np.array(dones, np.uint8)
+            out[k + "_states"] = np.array(states)
+            # a mid-game position under the 8 symmetries, and the action map
+            mid = GEnv(size, need)
+            for a in acts[: max(1, len(acts) // 2)]:
+                mid.step(a)
+            out[k + "_sym_boards"] = np.array([np.asarray(mid.apply_symmetry(sid).board).astype(np.int8) for sid in range(8)])
+            out[k + "_sym_actions"] = np.array([[mid.inverse_symmetry_action(sid, a) for a in range(size * size)]
+                                                for sid in range(8)], np.int32)
+            # position imported through the board setter: side to move and result are re-derived
+            imp = GEnv(size, need)
+            imp.board = boards[-1].astype(np.float32)
+            out[k + "_import"] = np.array([imp.turn, imp.winPlayer(), int(imp.done()), int(imp.check_full())], np.int32)
+    save("g1_gomoku_logic", **out)
+
+
 # ------------------------------------------------------------------ Othello (config 4)
 def gen_othello():
     from src.env_cpp.othello import Env as OEnv
@@ -309,8 +345,8 @@ def gen_othello():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rng", "g1", "g2", "search", "g6", "rollout", "g7", "g8", "g10", "othello"]
+    which = sys.argv[1:] or ["rng", "g1", "g2", "search", "g6", "rollout", "g7", "g8", "g10", "gomoku", "othello"]
     fns = dict(rng=gen_rng, g1=gen_g1, g2=gen_g2, search=gen_search, g6=gen_g6,
-               rollout=gen_rollout, g7=gen_g7, g8=gen_g8, g10=gen_g10, othello=gen_othello)
+               rollout=gen_rollout, g7=gen_g7, g8=gen_g8, g10=gen_g10, gomoku=gen_gomoku, othello=gen_othello)
     for w in which:
         fns[w]()

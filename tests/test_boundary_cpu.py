@@ -275,3 +275,63 @@ def test_othello_env_against_reference_fixture(built):
     cls = mcts_cpp.BatchedMCTS_Othello
     assert (cls.action_size, cls.board_size, tuple(cls.board_shape)) == (65, 64, (8, 8))
     assert hasattr(mcts_cpp, "RolloutEvaluator_Othello")
+
+
+def test_gomoku_env_against_reference_fixture(built):
+    """`src.env_cpp.gomoku.Env` (surface only - the reference binds no Gomoku search): random
+    games on six board / win-length configurations replayed against what the reference's
+    compiled Env produced (fixture g1_gomoku_logic): boards, side to move, result, NN planes,
+    the eight symmetries, the action map, re-import through the board setter, pickling and the
+    error messages of Gomoku.h."""
+    from src.env_cpp.gomoku import Env
+    g = load("g1_gomoku_logic")
+    keys = sorted({k.rsplit("_cfg", 1)[0] for k in g.files if k.endswith("_cfg")})
+    assert len(keys) == 18
+    for k in keys:
+        size, need = (int(v) for v in g[k + "_cfg"])
+        e = Env(size, need)
+        assert (e.board_size, e.rows, e.cols, e.n_in_row, e.action_size, e.num_symmetries) == (size, size, size, need, size * size, 8)
+        acts = g[k + "_actions"]
+        for t, a in enumerate(acts):
+            assert not e.done() and e.valid_mask()[a] and a in e.valid_move()
+            if t % 2:
+                e.step(int(a))
+            else:
+                e.step_xy(*e.action_to_coord(int(a)))
+            assert np.array_equal(np.asarray(e.board), g[k + "_boards"][t].astype(np.float32)) and e.board.dtype == np.float32
+            assert (e.turn, e.winPlayer(), e.check_winner(), int(e.done())) == (
+                int(g[k + "_turns"][t]), int(g[k + "_winners"][t]), int(g[k + "_winners"][t]), int(g[k + "_dones"][t]))
+            st = e.current_state()
+            assert st.shape == (1, 3, size, size) and st.dtype == np.float32
+            assert np.array_equal(st[0].astype(np.int8), g[k + "_states"][t])
+        with pytest.raises(RuntimeError, match="game is already finished"):
+            e.step(0)
+        mid = Env(size, need)
+        for a in acts[: max(1, len(acts) // 2)]:
+            mid.step(int(a))
+        for sid in range(8):
+            assert np.array_equal(np.asarray(mid.apply_symmetry(sid).board).astype(np.int8), g[k + "_sym_boards"][sid])
+            assert [mid.inverse_symmetry_action(sid, a) for a in range(size * size)] == list(g[k + "_sym_actions"][sid])
+        c = mid.copy()
+        c.apply_symmetry(3, inplace=True)
+        assert np.array_equal(np.asarray(c.board).astype(np.int8), g[k + "_sym_boards"][3])
+        imp = Env(g[k + "_boards"][-1].astype(np.float32), need)
+        assert [imp.turn, imp.winPlayer(), int(imp.done()), int(imp.check_full())] == list(g[k + "_import"])
+        p = pickle.loads(pickle.dumps(mid))
+        assert p.turn == mid.turn and p.n_in_row == need and np.array_equal(p.board, mid.board)
+    e = Env()
+    assert (e.board_size, e.n_in_row, Env.NUM_SYMMETRIES) == (15, 5, 8)
+    for bad, msg in (((0, 5), "board_size must be positive"), ((5, 1), "n_in_row must be >= 2"), ((4, 5), "n_in_row must be <= board size")):
+        with pytest.raises(RuntimeError, match=msg):
+            Env(*bad)
+    e.step(7)
+    for fn, msg in ((lambda: e.step(7), "cell is already occupied"), (lambda: e.step(225), "action out of range"),
+                    (lambda: e.coord_to_action(15, 0), "row/col out of range"), (lambda: e.apply_symmetry(8), "invalid symmetry id")):
+        with pytest.raises(RuntimeError, match=msg):
+            fn()
+    with pytest.raises(RuntimeError, match="turn must be 1 or -1"):
+        e.turn = 0
+    with pytest.raises(RuntimeError, match="board must be square"):
+        Env(np.zeros((3, 4), np.float32))
+    e.set_params(6, 4)
+    assert e.action_size == 36 and e.turn == 1 and e.valid_mask().count(True) == 36
