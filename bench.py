@@ -138,10 +138,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the search engine has no CPU path)")
+    # rehearsal of the multi-rank path on a one-GPU box: AZ_BENCH_REHEARSE=1 puts every rank on
+    # cuda:0 and exchanges the counters over gloo (RCCL cannot open one device twice)
+    rehearse = os.environ.get("AZ_BENCH_REHEARSE", "0") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))   # RCCL
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))   # RCCL
 
     import __graft_entry__ as ge
     if rank == 0 and not os.path.exists(os.path.join(PKG, "lib", "libaz_mcts.so")):
@@ -199,7 +207,7 @@ def main():
     # one collective: sum the counters, max the time (xGMI, a few dozen bytes)
     from src.shard import reduce_counters
     totals, t = reduce_counters([positions, cnt["sims"], cnt["expansions"], games, cnt["levels"],
-                                 cnt["backup_nodes"]], elapsed, dev)
+                                 cnt["backup_nodes"]], elapsed, torch.device("cpu") if rehearse else dev)
     g_pos, g_sims, g_exp, g_games = totals["positions"], totals["sims"], totals["expansions"], totals["games"]
 
     if rank == 0:
