@@ -231,7 +231,7 @@ def test_mfma_conv_block_matches_torch(env):
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     g = torch.Generator(device="cuda"); g.manual_seed(1)
     bf = torch.bfloat16
-    for B in (8, 37, 1024):                       # full tiles, a ragged tail, many tiles per workgroup
+    for B in (1, 8, 37, 1024, 6150):             # one sample, full tiles, ragged tails, several tiles per workgroup
         for cin, norm, resid in ((64, True, True), (64, True, False), (32, False, False)):
             x = (torch.randn(B, 42, cin, device="cuda", generator=g) * 1.5 + 0.3).to(bf)
             w = (torch.randn(64, cin, 3, 3, device="cuda", generator=g) / (3.0 * cin ** 0.5)).to(bf)
@@ -270,7 +270,7 @@ def test_mfma_attention_block_matches_torch(env):
     rnd = lambda *sh: torch.randn(*sh, device="cuda", generator=g)     # noqa: E731
     pre = (1 + 0.1 * rnd(64)).to(bf); qn = (1 + 0.1 * rnd(16)).to(bf); kn = (1 + 0.1 * rnd(16)).to(bf)
     wqkvg = (rnd(196, 64) / 8).to(bf); wo = (rnd(64, 64) / 8).to(bf)
-    for B in (1, 5, 4096):
+    for B in (1, 5, 4096, 9001):                 # 9001: more than one sample per wavefront of the grid, ragged
         x = (rnd(B, 42, 64) * 1.2).to(bf)
         y = torch.full_like(x, float("nan"))
         assert L.az_nn_attn_block(x.data_ptr(), pre.data_ptr(), wqkvg.data_ptr(), qn.data_ptr(), kn.data_ptr(),
