@@ -165,6 +165,11 @@ struct az_mcts {
     DevBuf<unsigned long long> counters;
     DevBuf<int> err;
     DevBuf<uint64_t> call_ctr;
+    // device transposition table of evaluator outputs (tt_kernels.hip)
+    DevBuf<az::TtEntry> tt_entries;
+    DevBuf<unsigned long long> tt_stats;
+    DevBuf<uint64_t> tt_keys;
+    uint64_t tt_mask = 0;
     int64_t select_launches = 0, backprop_launches = 0;
     bool profiling = false;
     EventRing ev_select, ev_backprop;
@@ -775,6 +780,79 @@ int az_mcts_dev_backprop(az_mcts *m, int K, int vl, const float *probs, const fl
         if (timed) m->ev_backprop.end(s);
         az::launch_bump_call(m->call_ctr.p, s);
         ++m->backprop_launches;
+    });
+}
+
+// ---- device transposition table ------------------------------------------------------------
+int az_mcts_dev_tt_create(az_mcts *m, int log2_entries)
+{
+    return guarded([&] {
+        require(m->game == AZ_GAME_CONNECT4, "dev_tt_create: the transposition table is built for Connect4 only");
+        require(log2_entries >= 2 && log2_entries <= 28, "dev_tt_create: log2_entries must be in [2, 28]");
+        HIP_OK(hipSetDevice(m->device));
+        HIP_OK(hipDeviceSynchronize());
+        const size_t n = static_cast<size_t>(1) << log2_entries;
+        if (n != m->tt_entries.n) {
+            if (m->tt_entries.p) { HIP_OK(hipFree(m->tt_entries.p)); m->tt_entries.p = nullptr; m->tt_entries.n = 0; }
+            m->tt_entries.ensure(n);
+            ++m->epoch;
+        }
+        HIP_OK(hipMemset(m->tt_entries.p, 0, n * sizeof(az::TtEntry)));
+        m->tt_stats.ensure(4, true);
+        HIP_OK(hipMemset(m->tt_stats.p, 0, 4 * sizeof(unsigned long long)));
+        m->tt_mask = n - 1;
+    });
+}
+
+int az_mcts_dev_tt_clear(az_mcts *m, void *stream)
+{
+    return guarded([&] {
+        require(m->tt_entries.p != nullptr, "dev_tt_clear: no table (az_mcts_dev_tt_create)");
+        HIP_OK(hipMemsetAsync(m->tt_entries.p, 0, m->tt_entries.n * sizeof(az::TtEntry), static_cast<hipStream_t>(stream)));
+    });
+}
+
+int az_mcts_dev_tt_lookup(az_mcts *m, int K, float *probs, float *wdl_rel, float *moves_left, int32_t *miss_idx,
+                          int64_t *miss_count, void *stream)
+{
+    return guarded([&] {
+        require(m->tt_entries.p != nullptr, "dev_tt_lookup: no table (az_mcts_dev_tt_create)");
+        LeafStore &ls = m->last_select_vl ? m->vl_leaf : m->plain_leaf;
+        const size_t total = static_cast<size_t>(m->B) * K;
+        require(K >= 1 && ls.slot.n >= total, "dev_tt_lookup: no selection of that width");
+        if (m->tt_keys.n < 2 * total) {
+            HIP_OK(hipDeviceSynchronize());
+            m->tt_keys.ensure(2 * total);
+            ++m->epoch;
+        }
+        az::TtTable t{m->tt_entries.p, m->tt_mask, m->tt_stats.p};
+        az::launch_tt_lookup(ls.view(), static_cast<int>(total), t, m->call_ctr.p, probs, wdl_rel, moves_left, miss_idx,
+                             miss_count, m->tt_keys.p, static_cast<hipStream_t>(stream));
+    });
+}
+
+int az_mcts_dev_tt_insert(az_mcts *m, int K, const int32_t *miss_idx, const int64_t *miss_count, const float *probs,
+                          const float *wdl_rel, const float *moves_left, void *stream)
+{
+    return guarded([&] {
+        require(m->tt_entries.p != nullptr, "dev_tt_insert: no table (az_mcts_dev_tt_create)");
+        const size_t total = static_cast<size_t>(m->B) * K;
+        require(K >= 1 && m->tt_keys.n >= 2 * total, "dev_tt_insert: call az_mcts_dev_tt_lookup on this selection first");
+        az::TtTable t{m->tt_entries.p, m->tt_mask, m->tt_stats.p};
+        az::launch_tt_insert(static_cast<int>(total), t, m->call_ctr.p, miss_idx, miss_count, m->tt_keys.p, probs, wdl_rel,
+                             moves_left, static_cast<hipStream_t>(stream));
+    });
+}
+
+int az_mcts_dev_tt_stats(az_mcts *m, int64_t out[4])
+{
+    return guarded([&] {
+        require(m->tt_entries.p != nullptr && out != nullptr, "dev_tt_stats: no table (az_mcts_dev_tt_create)");
+        HIP_OK(hipSetDevice(m->device));
+        HIP_OK(hipDeviceSynchronize());
+        unsigned long long h[4];
+        HIP_OK(hipMemcpy(h, m->tt_stats.p, sizeof(h), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 4; ++i) out[i] = static_cast<int64_t>(h[i]);
     });
 }
 

@@ -78,6 +78,19 @@ struct EvalIn {
     const float   *root_noise;
 };
 
+// Device transposition table (tt_kernels.hip): 64-byte entries, buckets of four
+constexpr int TT_VALUES = 11;                       // policy[7], relative wdl[3], moves left
+struct alignas(64) TtEntry {
+    uint64_t k0, k1;                                // key XOR checksum(value)
+    float    v[TT_VALUES];
+    uint32_t stamp;                                 // call counter at the last insert / hit
+};
+struct TtTable {
+    TtEntry *e;
+    uint64_t mask;                                  // entries - 1 (entries = power of two >= 4)
+    unsigned long long *stats;                      // lookups, hits, inserts, replaced
+};
+
 enum : int { CNT_SIMS = 0, CNT_LEVELS, CNT_EXPANSIONS, CNT_TERMINAL, CNT_DUP, CNT_BACKUP,
              CNT_SELECT_LAUNCHES, CNT_BACKPROP_LAUNCHES, CNT_N };
 
@@ -106,5 +119,10 @@ void launch_rollout(int game, LeafBuf lf, SearchParams p, int B, float *policy, 
                     float *ml, uint8_t *is_term, hipStream_t s);
 void launch_game_step(int game, uint64_t *bb0, uint64_t *bb1, int32_t *turns, const int32_t *actions,
                       uint8_t *done, int32_t *winner, int64_t n, bool reset_finished, hipStream_t s);
+
+void launch_tt_lookup(LeafBuf lf, int n_leaves, TtTable t, const uint64_t *clock, float *probs, float *wdl, float *ml,
+                      int32_t *miss_idx, int64_t *miss_count, uint64_t *keys, hipStream_t s);
+void launch_tt_insert(int n_leaves, TtTable t, const uint64_t *clock, const int32_t *miss_idx, const int64_t *miss_count,
+                      const uint64_t *keys, const float *probs, const float *wdl, const float *ml, hipStream_t s);
 
 }  // namespace az

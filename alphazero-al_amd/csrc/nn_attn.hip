@@ -87,8 +87,9 @@ __device__ __forceinline__ float col_max(float v)
 // qkvg: (196, 64) row-major [out][in]: rows 0-63 Q, 64-127 K, 128-191 V, 192-195 gate
 __global__ void __launch_bounds__(256, 2) k_attn_block(const uint16_t *x, const uint16_t *pre_w, const uint16_t *qkvg,
                                                     const uint16_t *qn_w, const uint16_t *kn_w, const uint16_t *o_w,
-                                                    uint16_t *y, int64_t B, float eps)
+                                                    uint16_t *y, int64_t B, float eps, const int64_t *batch_dev)
 {
+    if (batch_dev != nullptr && *batch_dev < B) B = *batch_dev;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -285,7 +286,8 @@ __global__ void __launch_bounds__(256, 2) k_attn_block(const uint16_t *x, const 
 extern "C" {
 
 int az_nn_attn_block(const void *x, const void *prenorm_w, const void *qkvg_w, const void *q_norm_w,
-                     const void *k_norm_w, const void *o_w, void *y, int64_t batch, float eps, void *stream)
+                     const void *k_norm_w, const void *o_w, void *y, int64_t batch, float eps, const int64_t *batch_dev,
+                     void *stream)
 {
     if (batch <= 0) return 1;
     const int64_t wgs = (batch + 3) / 4;
@@ -294,7 +296,7 @@ int az_nn_attn_block(const void *x, const void *prenorm_w, const void *qkvg_w, c
                        static_cast<const uint16_t *>(x), static_cast<const uint16_t *>(prenorm_w),
                        static_cast<const uint16_t *>(qkvg_w), static_cast<const uint16_t *>(q_norm_w),
                        static_cast<const uint16_t *>(k_norm_w), static_cast<const uint16_t *>(o_w),
-                       static_cast<uint16_t *>(y), batch, eps);
+                       static_cast<uint16_t *>(y), batch, eps, batch_dev);
     return 0;
 }
 

@@ -141,8 +141,9 @@ __device__ unsigned long long g_prof[2048 * 8];
 template <int CIN, bool NORM, bool RESID>
 __global__ void __launch_bounds__(256, 2) k_conv_block(const uint16_t *x, const uint16_t *w, const uint16_t *bias,
                                                        const uint16_t *gamma, const uint16_t *beta, uint16_t *y,
-                                                       int64_t B, float eps, int dbg)
+                                                       int64_t B, float eps, int dbg, const int64_t *batch_dev)
 {
+    if (batch_dev != nullptr && *batch_dev < B) B = *batch_dev;       // compact batch whose size only the device knows
     constexpr int K = 9 * CIN;
     constexpr int KSTEPS = K / 32;                // 18 (C_in 64) or 9 (C_in 32)
     constexpr int KPT = CIN / 32;                 // k steps per tap
@@ -447,7 +448,7 @@ int g_dbg = 0;   // timing experiments only (az_nn_debug): 1 skips the MFMA loop
 
 template <int CIN, bool NORM, bool RESID>
 int launch(const void *x, const void *w, const void *bias, const void *gamma, const void *beta, void *y, int64_t B,
-           float eps, hipStream_t s)
+           float eps, const int64_t *batch_dev, hipStream_t s)
 {
     constexpr size_t smem = static_cast<size_t>(TS) * PCELLS * CELLB + 2 * static_cast<size_t>(TS) * CELLS * CIN * 2 +
                             (RESID ? 0 : static_cast<size_t>(TS) * CELLS * COUT * 2) + 2 * CIN * sizeof(float) + 512;
@@ -470,7 +471,7 @@ int launch(const void *x, const void *w, const void *bias, const void *gamma, co
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, static_cast<const uint16_t *>(x),
                        static_cast<const uint16_t *>(w), static_cast<const uint16_t *>(bias),
                        static_cast<const uint16_t *>(gamma), static_cast<const uint16_t *>(beta),
-                       static_cast<uint16_t *>(y), B, eps, g_dbg);
+                       static_cast<uint16_t *>(y), B, eps, g_dbg, batch_dev);
     return 0;
 }
 
@@ -487,14 +488,15 @@ int az_nn_conv_profile(unsigned long long *out, int n)
 }
 
 int az_nn_conv_block(const void *x, int c_in, const void *weight_ohwi, const void *bias, const void *gamma,
-                     const void *beta, int residual, void *y, int64_t batch, float eps, void *stream)
+                     const void *beta, int residual, void *y, int64_t batch, float eps, const int64_t *batch_dev,
+                     void *stream)
 {
     if (batch <= 0) return 1;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool norm = gamma != nullptr && beta != nullptr;
-    if (c_in == 64 && norm && residual) return launch<64, true, true>(x, weight_ohwi, bias, gamma, beta, y, batch, eps, s);
-    if (c_in == 64 && norm && !residual) return launch<64, true, false>(x, weight_ohwi, bias, gamma, beta, y, batch, eps, s);
-    if (c_in == 32 && !norm && !residual) return launch<32, false, false>(x, weight_ohwi, bias, gamma, beta, y, batch, eps, s);
+    if (c_in == 64 && norm && residual) return launch<64, true, true>(x, weight_ohwi, bias, gamma, beta, y, batch, eps, batch_dev, s);
+    if (c_in == 64 && norm && !residual) return launch<64, true, false>(x, weight_ohwi, bias, gamma, beta, y, batch, eps, batch_dev, s);
+    if (c_in == 32 && !norm && !residual) return launch<32, false, false>(x, weight_ohwi, bias, gamma, beta, y, batch, eps, batch_dev, s);
     return 1;
 }
 

@@ -141,8 +141,10 @@ constexpr int L_MEAN = L_SCORE + WPB * 48 * 4;           // per wave: float [2][
 constexpr int L_TOTAL = L_MEAN + WPB * 2 * C * 4;
 
 __global__ void __launch_bounds__(64 * WPB) k_heads(const uint16_t *tok, az_nn_heads_weights w, const uint8_t *mask,
-                                                    float *probs, float *wdl, float *moves_left, int64_t B, float eps)
+                                                    float *probs, float *wdl, float *moves_left, int64_t B, float eps,
+                                                    const int32_t *scatter, const int64_t *batch_dev)
 {
+    if (batch_dev != nullptr && *batch_dev < B) B = *batch_dev;
     extern __shared__ __align__(16) uint8_t smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -299,8 +301,10 @@ __global__ void __launch_bounds__(64 * WPB) k_heads(const uint16_t *tok, az_nn_h
         }
 
         // ======== both samples of the pair: columns 0-6 | 7 and 8-14 | 15 of the B operand ========
-        const int64_t b = 2 * pr + half;              // the sample this lane's column belongs to
-        const bool real = b < B;
+        const int64_t bc = 2 * pr + half;             // the sample this lane's column belongs to
+        const bool real = bc < B;
+        // compact batch: sample bc stands for row scatter[bc] of the mask and of the outputs
+        const int64_t b = (real && scatter != nullptr) ? scatter[bc] : bc;
         const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
         f32x4 ap[4], ad[4];
         {
@@ -401,7 +405,8 @@ __global__ void __launch_bounds__(64 * WPB) k_heads(const uint16_t *tok, az_nn_h
 }  // namespace
 
 extern "C" int az_nn_heads(const void *tokens, const az_nn_heads_weights *w, const uint8_t *mask, float *probs,
-                           float *wdl, float *moves_left, int64_t batch, float eps, void *stream)
+                           float *wdl, float *moves_left, int64_t batch, float eps, const int32_t *scatter,
+                           const int64_t *batch_dev, void *stream)
 {
     if (batch <= 0 || w == nullptr || tokens == nullptr || probs == nullptr || wdl == nullptr || moves_left == nullptr) return 1;
     static bool attr_set = false;
@@ -415,6 +420,6 @@ extern "C" int az_nn_heads(const void *tokens, const az_nn_heads_weights *w, con
     const int64_t want = ((batch + 1) / 2 + WPB - 1) / WPB;
     const unsigned grid = static_cast<unsigned>(want < 512 ? want : 512);
     hipLaunchKernelGGL(k_heads, dim3(grid), dim3(64 * WPB), L_TOTAL, static_cast<hipStream_t>(stream),
-                       static_cast<const uint16_t *>(tokens), *w, mask, probs, wdl, moves_left, batch, eps);
+                       static_cast<const uint16_t *>(tokens), *w, mask, probs, wdl, moves_left, batch, eps, scatter, batch_dev);
     return 0;
 }

@@ -53,16 +53,19 @@ __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __exp
 // tokens[b, cell, :] = pos[cell, :] + own * e_own + opp * e_opp      (Network.py:226-239)
 template <int E>
 __global__ void __launch_bounds__(256) k_embed(const float *feat, const uint16_t *e_own, const uint16_t *e_opp,
-                                               const uint16_t *pos, uint16_t *tokens, int64_t B)
+                                               const uint16_t *pos, uint16_t *tokens, int64_t B,
+                                               const int32_t *gather, const int64_t *batch_dev)
 {
     constexpr int VPT = E / 8;
+    if (batch_dev != nullptr && *batch_dev < B) B = *batch_dev;
     const int64_t gid = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const int64_t tok = gid / VPT;
     const int vec = static_cast<int>(gid - tok * VPT);
     if (tok >= B * CELLS) return;
     const int64_t b = tok / CELLS;
     const int cell = static_cast<int>(tok - b * CELLS);
-    const float own = feat[b * 3 * CELLS + cell], opp = feat[b * 3 * CELLS + CELLS + cell];
+    const int64_t src = gather != nullptr ? gather[b] : b;       // row of `feat` that sample b of the compact batch shows
+    const float own = feat[src * 3 * CELLS + cell], opp = feat[src * 3 * CELLS + CELLS + cell];
     float p[8], a[8], o[8], r[8];
     unpack8(*reinterpret_cast<const V8 *>(pos + cell * E + vec * 8), p);
     unpack8(*reinterpret_cast<const V8 *>(e_own + vec * 8), a);
@@ -328,11 +331,11 @@ inline uint16_t *u16(void *p) { return static_cast<uint16_t *>(p); }
 extern "C" {
 
 int az_nn_embed(const float *features, const void *emb_own, const void *emb_opp, const void *pos, void *tokens,
-                int64_t batch, int embed_dim, void *stream)
+                int64_t batch, int embed_dim, const int32_t *gather, const int64_t *batch_dev, void *stream)
 {
     if (embed_dim != 32 || batch <= 0) return 1;
     hipLaunchKernelGGL(k_embed<32>, dim3(blocks(batch * CELLS * 4, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       features, u16(emb_own), u16(emb_opp), u16(pos), u16(tokens), batch);
+                       features, u16(emb_own), u16(emb_opp), u16(pos), u16(tokens), batch, gather, batch_dev);
     return 0;
 }
 

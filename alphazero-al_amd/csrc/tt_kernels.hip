@@ -1,0 +1,158 @@
+// tt_kernels.hip - device transposition table of evaluator outputs (Connect4).
+//
+// What the reference keeps in a Python OrderedDict (src/Cache.py:5-58, used per leaf by
+// src/MCTS_cpp.py:146-189 and 298-339): key = the leaf position AS THE EVALUATOR SEES IT (the
+// symmetrised board) + side to move, value = (policy[7], relative wdl[3], moves left).  Here:
+// a flat open-addressing table in HBM, 64-byte entries, 4-entry buckets (one 256-byte line).
+//
+//   lookup   one thread per leaf: hit -> the cached 11 floats go straight into the arrays the
+//            backup kernel reads; miss -> the leaf's index is appended to a compact list whose
+//            length stays on the device (the evaluator kernels size their work from it).
+//   insert   one thread per miss, after the evaluator ran: bucket slot = same key, else empty,
+//            else the entry with the oldest stamp (approximate LRU).
+//
+// Entries are written with no lock.  The stored key is XORed with a checksum of the value, so an
+// entry torn by two concurrent writers fails the comparison and reads as a miss: a lookup never
+// returns a value that was not evaluated for exactly that key.  Because the evaluator kernels
+// compute every sample independently of its batch (bit-identical outputs for identical inputs),
+// a search with the table visits exactly the nodes it visits without it.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "games.h"
+#include "kernels.h"
+
+namespace az {
+namespace {
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x)
+{
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull;
+    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull;
+    x ^= x >> 33;
+    return x;
+}
+
+__device__ __forceinline__ uint64_t mirror_columns(uint64_t b)       // 7 bits per column (Connect4.h:249-262)
+{
+    uint64_t r = 0;
+#pragma unroll
+    for (int c = 0; c < 7; ++c) r |= ((b >> (7 * c)) & 0x7full) << (7 * (6 - c));
+    return r;
+}
+
+// the evaluator's view of a leaf: stones of the side to move, stones of the opponent, who moves
+__device__ __forceinline__ void leaf_key(const LeafBuf &lf, int64_t leaf, uint64_t &k0, uint64_t &k1)
+{
+    uint64_t p1 = lf.bb0[leaf], p2 = lf.bb1[leaf];
+    if (lf.sym[leaf]) { p1 = mirror_columns(p1); p2 = mirror_columns(p2); }
+    const bool first = lf.turn[leaf] > 0;
+    k0 = (first ? p1 : p2) | (first ? (1ull << 63) : 0ull);
+    k1 = (first ? p2 : p1) | (1ull << 62);                           // never zero: an empty entry matches nothing
+}
+
+__device__ __forceinline__ uint64_t value_sum(const float *v)
+{
+    uint64_t c = 0x9e3779b97f4a7c15ull;
+#pragma unroll
+    for (int i = 0; i < TT_VALUES; ++i) c = mix64(c ^ __float_as_uint(v[i])) + i;
+    return c;
+}
+
+__global__ void __launch_bounds__(256) k_tt_lookup(LeafBuf lf, int n_leaves, TtTable t, const uint64_t *clock,
+                                                   float *probs, float *wdl, float *ml, int32_t *miss_idx,
+                                                   int64_t *miss_count, uint64_t *keys)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const bool in = i < n_leaves;
+    bool miss = false, hit = false;
+    if (in && !(lf.flags[i] & LEAF_TERMINAL)) {           // terminal leaves take their result from the game
+        uint64_t k0, k1;
+        leaf_key(lf, i, k0, k1);
+        keys[2 * i] = k0;
+        keys[2 * i + 1] = k1;
+        const uint64_t bucket = (mix64(k0 ^ mix64(k1)) & t.mask) & ~3ull;
+        miss = true;
+        for (int j = 0; j < 4 && miss; ++j) {
+            TtEntry e = t.e[bucket + j];
+            const uint64_t c = value_sum(e.v);
+            if ((e.k0 ^ c) == k0 && (e.k1 ^ (c << 17 | c >> 47)) == k1) {
+                miss = false;
+                hit = true;
+#pragma unroll
+                for (int a = 0; a < 7; ++a) probs[i * 7 + a] = e.v[a];
+                wdl[i * 3 + 0] = e.v[7]; wdl[i * 3 + 1] = e.v[8]; wdl[i * 3 + 2] = e.v[9];
+                ml[i] = e.v[10];
+                t.e[bucket + j].stamp = static_cast<uint32_t>(*clock);      // recently used
+            }
+        }
+    }
+    // one atomic per wavefront for the compact list, one for the statistics
+    const unsigned long long mm = __ballot(miss), hm = __ballot(hit);
+    const int lane = threadIdx.x & 63;
+    int64_t base = 0;
+    if (lane == 0) {
+        if (mm) base = static_cast<int64_t>(atomicAdd(reinterpret_cast<unsigned long long *>(miss_count),
+                                                      static_cast<unsigned long long>(__popcll(mm))));
+        if (mm | hm) {
+            atomicAdd(&t.stats[0], static_cast<unsigned long long>(__popcll(mm) + __popcll(hm)));
+            if (hm) atomicAdd(&t.stats[1], static_cast<unsigned long long>(__popcll(hm)));
+        }
+    }
+    base = __shfl(base, 0, 64);
+    if (miss) miss_idx[base + __popcll(mm & ((1ull << lane) - 1))] = static_cast<int32_t>(i);
+}
+
+__global__ void __launch_bounds__(256) k_tt_insert(TtTable t, const uint64_t *clock, const int32_t *miss_idx,
+                                                   const int64_t *miss_count, const uint64_t *keys, const float *probs,
+                                                   const float *wdl, const float *ml)
+{
+    const int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (j >= *miss_count) return;
+    const int64_t i = miss_idx[j];
+    const uint64_t k0 = keys[2 * i], k1 = keys[2 * i + 1];
+    TtEntry e;
+#pragma unroll
+    for (int a = 0; a < 7; ++a) e.v[a] = probs[i * 7 + a];
+    e.v[7] = wdl[i * 3 + 0]; e.v[8] = wdl[i * 3 + 1]; e.v[9] = wdl[i * 3 + 2];
+    e.v[10] = ml[i];
+    const uint64_t c = value_sum(e.v);
+    e.k0 = k0 ^ c;
+    e.k1 = k1 ^ (c << 17 | c >> 47);
+    const uint32_t now = static_cast<uint32_t>(*clock);
+    e.stamp = now;
+    const uint64_t bucket = (mix64(k0 ^ mix64(k1)) & t.mask) & ~3ull;
+    int victim = 0;
+    uint32_t oldest = 0;
+    bool replaced = true;
+    for (int s = 0; s < 4; ++s) {
+        const TtEntry cur = t.e[bucket + s];
+        if (cur.k0 == e.k0 && cur.k1 == e.k1) { victim = s; replaced = false; break; }      // same key, same value
+        const bool empty = cur.k0 == 0 && cur.k1 == 0;
+        const uint32_t age = empty ? 0xffffffffu : now - cur.stamp;
+        if (s == 0 || age > oldest) { oldest = age; victim = s; replaced = !empty; }
+    }
+    t.e[bucket + victim] = e;
+    atomicAdd(&t.stats[2], 1ull);
+    if (replaced) atomicAdd(&t.stats[3], 1ull);
+}
+
+}  // namespace
+
+void launch_tt_lookup(LeafBuf lf, int n_leaves, TtTable t, const uint64_t *clock, float *probs, float *wdl, float *ml,
+                      int32_t *miss_idx, int64_t *miss_count, uint64_t *keys, hipStream_t s)
+{
+    (void)hipMemsetAsync(miss_count, 0, sizeof(int64_t), s);
+    hipLaunchKernelGGL(k_tt_lookup, dim3((n_leaves + 255) / 256), dim3(256), 0, s, lf, n_leaves, t, clock, probs, wdl, ml,
+                       miss_idx, miss_count, keys);
+}
+
+void launch_tt_insert(int n_leaves, TtTable t, const uint64_t *clock, const int32_t *miss_idx, const int64_t *miss_count,
+                      const uint64_t *keys, const float *probs, const float *wdl, const float *ml, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_tt_insert, dim3((n_leaves + 255) / 256), dim3(256), 0, s, t, clock, miss_idx, miss_count, keys,
+                       probs, wdl, ml);
+}
+
+}  // namespace az

@@ -36,16 +36,16 @@ def glue():
         try:
             L = C.CDLL(path)
             vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
-            L.az_nn_embed.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp]
+            L.az_nn_embed.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp, vp, vp]
             L.az_nn_groupnorm1.argtypes = [vp, vp, vp, vp, i64, i32, f32, vp]
             L.az_nn_silu_add.argtypes = [vp, vp, i32, vp, vp, i64, vp]
             L.az_nn_rmsnorm64.argtypes = [vp, vp, vp, i64, f32, vp]
             L.az_nn_qkv_prep.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i64, f32, vp]
             L.az_nn_attn_post.argtypes = [vp, vp, vp, i64, vp]
             L.az_nn_heads_prep.argtypes = [vp, vp, vp, f32, vp, vp, i64, f32, vp]
-            L.az_nn_conv_block.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, i64, f32, vp]
-            L.az_nn_attn_block.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, f32, vp]
-            L.az_nn_heads.argtypes = [vp, C.POINTER(HeadsWeights), vp, vp, vp, vp, i64, f32, vp]
+            L.az_nn_conv_block.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, i64, f32, vp, vp]
+            L.az_nn_attn_block.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, f32, vp, vp]
+            L.az_nn_heads.argtypes = [vp, C.POINTER(HeadsWeights), vp, vp, vp, vp, i64, f32, vp, vp, vp]
             _GLUE = L
         except OSError:
             _GLUE = False
@@ -175,10 +175,27 @@ class FastConnect4Net(torch.nn.Module):
         img = tokens.view(bsz, ROWS, COLS, cin).permute(0, 3, 1, 2)
         return F.conv2d(img, w, None, padding=1).permute(0, 2, 3, 1)         # (B, 6, 7, Cout) view
 
+    @property
+    def supports_compact(self):
+        """predict_device(..., rows=, n_rows=, out=): evaluate only the listed rows"""
+        return bool(self.hip and self.fused_heads)
+
     @torch.no_grad()
-    def predict_device(self, x, action_mask=None):
+    def predict_device(self, x, action_mask=None, rows=None, n_rows=None, out=None):
         """(probs (B,7), wdl (B,3) relative [draw, win, loss], moves_left (B,)) fp32 on the device:
-        what the reference's `predict` returns (Network.py:267-288) without the host copies."""
+        what the reference's `predict` returns (Network.py:267-288) without the host copies.
+        Compact form (HIP path only): `rows` int32 (B,) and `n_rows` int64 () on the device name
+        the rows of x / action_mask to evaluate - the first n_rows entries of rows - and only those
+        rows of `out` = (probs, wdl, ml) are written; the cost follows n_rows, not B."""
+        if rows is not None:
+            assert self.supports_compact and out is not None and n_rows is not None
+            t, bsz, L, s = self._body_hip(x, rows, n_rows)
+            probs, wdl, ml = out
+            m = action_mask.contiguous()
+            L.az_nn_heads(t.data_ptr(), C.byref(self._heads_w), m.data_ptr(), probs.data_ptr(), wdl.data_ptr(),
+                          ml.data_ptr(), bsz, 1e-5, rows.data_ptr(), n_rows.data_ptr(), s)
+            self._keep_mask = m
+            return probs, wdl, ml
         if not (self.hip and x.is_cuda):
             lp, v, st = self(x, action_mask)
             return lp.exp(), v.exp(), st * float(self.aux_target_offset)
@@ -194,7 +211,7 @@ class FastConnect4Net(torch.nn.Module):
             m = action_mask if action_mask.dtype in (torch.uint8, torch.bool) else action_mask.to(torch.bool)
             m = m.contiguous()
         L.az_nn_heads(t.data_ptr(), C.byref(self._heads_w), None if m is None else m.data_ptr(), probs.data_ptr(),
-                      wdl.data_ptr(), ml.data_ptr(), bsz, 1e-5, s)
+                      wdl.data_ptr(), ml.data_ptr(), bsz, 1e-5, None, None, s)
         self._keep_mask = m
         return probs, wdl, ml
 
@@ -206,9 +223,12 @@ class FastConnect4Net(torch.nn.Module):
         return self._forward_hip_glue(x, action_mask)
 
     @torch.no_grad()
-    def _body_hip(self, x):
-        """embedding, stem, residual blocks and attention on the MFMA kernels -> final tokens"""
+    def _body_hip(self, x, rows=None, n_rows=None):
+        """embedding, stem, residual blocks and attention on the MFMA kernels -> final tokens
+        (of the compact batch when rows / n_rows are given)"""
         L = glue()
+        gp = None if rows is None else rows.data_ptr()
+        np_ = None if n_rows is None else n_rows.data_ptr()
         s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         bsz = x.shape[0]
         dev, bf = self.device, torch.bfloat16
@@ -216,19 +236,19 @@ class FastConnect4Net(torch.nn.Module):
         x = x.contiguous().float()
         t0 = torch.empty((bsz, CELLS, self.embed_dim), dtype=bf, device=dev)
         L.az_nn_embed(x.data_ptr(), self.emb_own.data_ptr(), self.emb_opp.data_ptr(), self.pos.data_ptr(),
-                      t0.data_ptr(), bsz, self.embed_dim, s)
+                      t0.data_ptr(), bsz, self.embed_dim, gp, np_, s)
         t = torch.empty((bsz, CELLS, c_dim), dtype=bf, device=dev)
         L.az_nn_conv_block(t0.data_ptr(), self.embed_dim, self.stem_w.data_ptr(), self.stem_b.data_ptr(), None,
-                           None, 0, t.data_ptr(), bsz, 1e-5, s)
+                           None, 0, t.data_ptr(), bsz, 1e-5, np_, s)
         for w, b, g, beta in self.res:
             t2 = torch.empty_like(t)
             L.az_nn_conv_block(t.data_ptr(), c_dim, getattr(self, w).data_ptr(), getattr(self, b).data_ptr(),
                                getattr(self, g).data_ptr(), getattr(self, beta).data_ptr(), 1, t2.data_ptr(),
-                               bsz, 1e-5, s)
+                               bsz, 1e-5, np_, s)
             t = t2
         t2 = torch.empty_like(t)
         L.az_nn_attn_block(t.data_ptr(), self.pre_w.data_ptr(), self.qkvg_w.data_ptr(), self.qn_w.data_ptr(),
-                           self.kn_w.data_ptr(), self.o_w.data_ptr(), t2.data_ptr(), bsz, 1e-5, s)
+                           self.kn_w.data_ptr(), self.o_w.data_ptr(), t2.data_ptr(), bsz, 1e-5, np_, s)
         return t2, bsz, L, s
 
     @torch.no_grad()
@@ -241,19 +261,19 @@ class FastConnect4Net(torch.nn.Module):
         x = x.contiguous().float()
         t = torch.empty((bsz, CELLS, self.embed_dim), dtype=bf, device=dev)
         L.az_nn_embed(x.data_ptr(), self.emb_own.data_ptr(), self.emb_opp.data_ptr(), self.pos.data_ptr(),
-                      t.data_ptr(), bsz, self.embed_dim, s)
+                      t.data_ptr(), bsz, self.embed_dim, None, None, s)
         n_el = bsz * CELLS * c_dim
         if self.mfma_conv:
             # each block is one MFMA kernel (nn_conv.hip)
             t0 = t
             t = torch.empty((bsz, CELLS, c_dim), dtype=bf, device=dev)
             L.az_nn_conv_block(t0.data_ptr(), self.embed_dim, self.stem_w.data_ptr(), self.stem_b.data_ptr(), None,
-                               None, 0, t.data_ptr(), bsz, 1e-5, s)
+                               None, 0, t.data_ptr(), bsz, 1e-5, None, s)
             for w, b, g, beta in self.res:
                 t2 = torch.empty_like(t)
                 L.az_nn_conv_block(t.data_ptr(), c_dim, getattr(self, w).data_ptr(), getattr(self, b).data_ptr(),
                                    getattr(self, g).data_ptr(), getattr(self, beta).data_ptr(), 1, t2.data_ptr(),
-                                   bsz, 1e-5, s)
+                                   bsz, 1e-5, None, s)
                 t = t2
             y = torch.empty_like(t)
         else:
@@ -273,7 +293,7 @@ class FastConnect4Net(torch.nn.Module):
         if self.mfma_attn:
             t2 = torch.empty_like(t)
             L.az_nn_attn_block(t.data_ptr(), self.pre_w.data_ptr(), self.qkvg_w.data_ptr(), self.qn_w.data_ptr(),
-                               self.kn_w.data_ptr(), self.o_w.data_ptr(), t2.data_ptr(), bsz, 1e-5, s)
+                               self.kn_w.data_ptr(), self.o_w.data_ptr(), t2.data_ptr(), bsz, 1e-5, None, s)
             return self._heads_hip(t2, action_mask, bsz, L, s)
         L.az_nn_rmsnorm64(t.data_ptr(), self.pre_w.data_ptr(), y.data_ptr(), rows, 1e-5, s)
         qkvg = F.linear(y.view(rows, c_dim), self.qkvg_w_pad)                 # (T, 200)

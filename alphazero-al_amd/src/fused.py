@@ -52,6 +52,11 @@ def lib():
         L.az_mcts_profile.argtypes = [vp, i32]
         L.az_mcts_profile_read.argtypes = [vp, C.POINTER(C.c_double * 2), C.POINTER(i64 * 2)]
         L.az_c4_dev_step.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, vp]
+        L.az_mcts_dev_tt_create.argtypes = [vp, i32]
+        L.az_mcts_dev_tt_clear.argtypes = [vp, vp]
+        L.az_mcts_dev_tt_lookup.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
+        L.az_mcts_dev_tt_insert.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
+        L.az_mcts_dev_tt_stats.argtypes = [vp, C.POINTER(i64 * 4)]
         _LIB = L
     return _LIB
 
@@ -133,6 +138,11 @@ class FusedSearch:
         self.fast = None
         self._fast_version = None
         self.use_fast = os.environ.get("AZ_FUSED_FASTNET", "1") != "0"
+        # device transposition table (enable_table): off unless asked for
+        self.table_log2 = 0
+        self.table_verify = False
+        self._tt_bufs = {}
+        self.tt_mismatch = None
 
     def _sync_fast_net(self):
         if not self.use_fast or hasattr(self.net, "predict_device"):
@@ -146,6 +156,65 @@ class FusedSearch:
             self._fast_version = version
             self._graphs.clear()        # captured graphs hold the old weight buffers
             self._eager_runs.clear()
+            if self.table_log2:         # cached outputs belong to the old weights (MCTS_cpp.py:361-377)
+                check(lib().az_mcts_dev_tt_clear(self.h, _stream()))
+
+    # ------------------------------------------------------------------ transposition table
+    def enable_table(self, log2_entries=20, verify=False):
+        """Keep evaluator outputs of positions already seen in a device hash table (include/az_mcts.h;
+        the reference's `cache_size`, src/Cache.py).  Needs an evaluator that can work on a compact
+        list of rows (the HIP inference twin); with it an iteration costs the leaves that MISS.
+        `verify=True` also evaluates every leaf densely and counts rows whose table value differs
+        from the fresh one (`tt_mismatch`, must stay 0: the evaluator is a pure function per row)."""
+        self._sync_fast_net()
+        if self.fast is None or not getattr(self.fast, "supports_compact", False):
+            raise RuntimeError("the device transposition table needs the HIP inference twin of the Connect4 network "
+                               "(a module with the reference CNN's parameters on a GPU)")
+        check(lib().az_mcts_dev_tt_create(self.h, int(log2_entries)))
+        self.table_log2 = int(log2_entries)
+        self.table_verify = bool(verify)
+        self.tt_mismatch = torch.zeros((), dtype=torch.int64, device=self.device)
+        self._graphs.clear()
+        self._eager_runs.clear()
+
+    def table_stats(self):
+        arr = (C.c_int64 * 4)()
+        check(lib().az_mcts_dev_tt_stats(self.h, C.byref(arr)))
+        d = dict(zip(("lookups", "hits", "inserts", "replaced"), list(arr)))
+        d["hit_rate"] = d["hits"] / d["lookups"] if d["lookups"] else 0.0
+        if self.tt_mismatch is not None:
+            d["mismatches"] = int(self.tt_mismatch.item())
+        return d
+
+    def _table_buffers(self, K):
+        if K not in self._tt_bufs:
+            n = self.B * K
+            z = dict(device=self.device)
+            self._tt_bufs[K] = (torch.zeros((n, self.A), dtype=torch.float32, **z), torch.zeros((n, 3), dtype=torch.float32, **z),
+                                torch.zeros((n,), dtype=torch.float32, **z), torch.zeros((n,), dtype=torch.int32, **z),
+                                torch.zeros((1,), dtype=torch.int64, **z))
+        return self._tt_bufs[K]
+
+    def _iteration_with_table(self, K, vl):
+        L = lib()
+        feats, mask = self._buffers(K)
+        probs, wdl, ml, rows, n_rows = self._table_buffers(K)
+        s = _stream()
+        check(L.az_mcts_dev_select(self.h, K, vl, feats.data_ptr(), mask.data_ptr(), s))
+        check(L.az_mcts_dev_tt_lookup(self.h, K, probs.data_ptr(), wdl.data_ptr(), ml.data_ptr(), rows.data_ptr(),
+                                      n_rows.data_ptr(), s))
+        self.fast.predict_device(feats, mask, rows=rows, n_rows=n_rows, out=(probs, wdl, ml))
+        check(L.az_mcts_dev_tt_insert(self.h, K, rows.data_ptr(), n_rows.data_ptr(), probs.data_ptr(), wdl.data_ptr(),
+                                      ml.data_ptr(), s))
+        keep = None
+        if self.table_verify:
+            p2, w2, m2 = self.fast.predict_device(feats, mask)
+            live = mask.view(torch.uint8).any(dim=1)                 # terminal leaves show an all-zero mask
+            bad = ((probs != p2).any(1) | (wdl != w2).any(1) | (ml != m2)) & live
+            self.tt_mismatch += bad.sum()
+            keep = (p2, w2, m2)
+        check(L.az_mcts_dev_backprop(self.h, K, vl, probs.data_ptr(), wdl.data_ptr(), ml.data_ptr(), s))
+        return keep
 
     # ------------------------------------------------------------------ pieces
     def _buffers(self, K):
@@ -176,6 +245,8 @@ class FusedSearch:
         return probs.contiguous(), wdl.contiguous(), ml.reshape(-1).contiguous()
 
     def _iteration(self, K, vl):
+        if self.table_log2:
+            return self._iteration_with_table(K, vl)
         L = lib()
         feats, mask = self._buffers(K)
         s = _stream()

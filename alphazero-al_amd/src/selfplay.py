@@ -39,7 +39,7 @@ class DeviceSelfPlay:
                  noise_epsilon=0.25, fpu_reduction=0.2, use_symmetry=True, mlh_slope=0.1, mlh_cap=0.2,
                  value_decay=1.0, temperature=1.0, temp_decay_moves=20, temp_endgame=0.0, seed=0,
                  reserve_slots=None, record=False, td_steps=0, refill=True, sampler="device",
-                 max_finished_games=None):
+                 max_finished_games=None, table_log2=0):
         self.B = int(n_games)
         self.n_playout = int(n_playout)
         self.vl_batch = int(vl_batch)
@@ -52,6 +52,8 @@ class DeviceSelfPlay:
                                   mlh_slope=mlh_slope, mlh_cap=mlh_cap, value_decay=value_decay)
         self.search.seed(seed)
         self.fused = F.FusedSearch(self.search, net)
+        if table_log2:
+            self.fused.enable_table(table_log2)         # the reference's cache_size (src/Cache.py), in HBM
         self.h = self.fused.h
         dev = self.fused.device
         self.device = dev

@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--vl-batch", type=int, default=4)
     ap.add_argument("--evaluator", choices=["cnn", "hash"], default="cnn",
                     help="cnn: the reference's network (headline); hash: integer hash evaluator (tree kernels only)")
+    ap.add_argument("--table", type=int, default=0, metavar="LOG2",
+                    help="device transposition table of 2^LOG2 evaluator outputs (the reference's cache_size, "
+                         "BASELINE config 4); OFF for the headline number, which evaluates every leaf")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-games", type=int, default=256)
     ap.add_argument("--cpu-plies", type=int, default=2)
@@ -168,7 +171,7 @@ def main():
     else:
         net = Connect4Net(device=dev).eval()
     sp = DeviceSelfPlay(net, args.games, n_playout=args.n_playout, vl_batch=args.vl_batch, seed=rank,
-                        reserve_slots=int(os.environ.get("AZ_RESERVE_SLOTS", "49152")))
+                        reserve_slots=int(os.environ.get("AZ_RESERVE_SLOTS", "49152")), table_log2=args.table)
     L = F.lib()
 
     log(f"rank {rank}: engine + evaluator ready ({args.games} games, n_playout={args.n_playout}, K={args.vl_batch})")
@@ -254,6 +257,11 @@ def main():
             "tree_kernels_share_of_step": round((sel_ms + bp_ms) / (elapsed * 1e3), 4),
             "roofline": roofline,
         }
+        if args.table:
+            st = sp.fused.table_stats()                  # whole run, warm-up included
+            out["config"]["workload"] += ", transposition table 2^%d entries" % args.table
+            out["transposition_table"] = {"entries": 1 << args.table, "lookups": st["lookups"], "hits": st["hits"],
+                                          "hit_rate": round(st["hit_rate"], 4), "replaced": st["replaced"]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, rank)
         print(json.dumps(out), flush=True)

@@ -163,6 +163,30 @@ int az_mcts_dev_reset_masked(az_mcts *m, const uint8_t *mask, void *stream);
 int az_c4_dev_step(uint64_t *bb_p1, uint64_t *bb_p2, int32_t *turns, const int32_t *actions,
                    uint8_t *done, int32_t *winner, int64_t n, int reset_finished, void *stream);
 
+/* ---- device transposition table of evaluator outputs (Connect4) -------------------------
+ * Replaces, for the device loop, the LRU table of the reference's wrapper (src/Cache.py:5-58 used
+ * by src/MCTS_cpp.py:146-189 and 298-339): key = the symmetrised leaf position + side to move,
+ * value = policy[7], relative wdl[3], moves left.  2^log2_entries entries of 64 bytes, buckets
+ * of four, approximate-LRU replacement inside a bucket.  Between az_mcts_dev_select and
+ * az_mcts_dev_backprop of one iteration:
+ *   az_mcts_dev_tt_lookup   hits: the cached values are written to probs / wdl_rel / moves_left
+ *                           at the leaf's flat index; misses: their flat indices are appended to
+ *                           miss_idx[0 .. *miss_count) (int32 [n*K] and int64 [1], DEVICE memory;
+ *                           the count is reset first).  Terminal leaves are neither.
+ *   (evaluate the rows listed in miss_idx, writing the same three arrays - az_nn.h `batch_dev`)
+ *   az_mcts_dev_tt_insert   stores the freshly evaluated rows.
+ * A lookup never returns a value that was not inserted for exactly its key (torn entries fail a
+ * checksum and read as misses).  az_mcts_dev_tt_clear empties the table: call it whenever the
+ * evaluator's weights change (MCTS_cpp.py:361-377 `refresh_cache` re-evaluates instead).
+ * Statistics (synchronises): lookups, hits, inserts, entries replaced. */
+int az_mcts_dev_tt_create(az_mcts *m, int log2_entries);
+int az_mcts_dev_tt_clear(az_mcts *m, void *stream);
+int az_mcts_dev_tt_lookup(az_mcts *m, int K, float *probs, float *wdl_rel, float *moves_left, int32_t *miss_idx,
+                          int64_t *miss_count, void *stream);
+int az_mcts_dev_tt_insert(az_mcts *m, int K, const int32_t *miss_idx, const int64_t *miss_count, const float *probs,
+                          const float *wdl_rel, const float *moves_left, void *stream);
+int az_mcts_dev_tt_stats(az_mcts *m, int64_t out[4]);
+
 /* ---- capacity / instrumentation ------------------------------------------------------- */
 
 /* Make every tree arena hold at least `slots` node records (grows, never shrinks). */

@@ -7,6 +7,13 @@
  * PyTorch kernels between its GEMM-shaped operations.  All tensors are DEVICE pointers to
  * contiguous bf16 data in token layout (batch, 42, channels) unless stated; `stream` is a
  * hipStream_t; every function only enqueues work and returns 0, or 1 on a bad argument.
+ *
+ * Compact batches: the four kernels of the forward pass (embed, conv_block, attn_block, heads)
+ * take `batch_dev`, a device pointer to an int64 (or NULL): when given, only the first
+ * min(batch, *batch_dev) samples are processed - `batch` sizes the launch, the device decides
+ * the work (the leaves that missed the transposition table, az_mcts.h).  `gather[b]` (embed)
+ * is the row of the feature tensor that compact sample b shows, `scatter[b]` (heads) the row
+ * of the mask and of the three output arrays it belongs to; NULL = identity.
  */
 #ifndef AZ_NN_H
 #define AZ_NN_H
@@ -20,7 +27,8 @@ extern "C" {
 /* tokens[b, cell, :] = pos[cell, :] + own(b, cell) * emb_own + opp(b, cell) * emb_opp
  * (Network.py:226-239).  features: float32 (batch, 3, 6, 7) relative planes; embed_dim 32. */
 int az_nn_embed(const float *features, const void *emb_own, const void *emb_opp, const void *pos,
-                void *tokens, int64_t batch, int embed_dim, void *stream);
+                void *tokens, int64_t batch, int embed_dim, const int32_t *gather, const int64_t *batch_dev,
+                void *stream);
 /* GroupNorm(num_groups=1) over each sample's 42*channels values + per-channel affine
  * (Network.py:38,44); channels 64. */
 int az_nn_groupnorm1(const void *x, const void *gamma, const void *beta, void *y, int64_t batch,
@@ -37,13 +45,15 @@ int az_nn_silu_add(const void *x, const void *bias, int channels, const void *re
  * (torch channels_last memory of the OIHW tensor).  gamma/beta NULL = no normalisation.
  * Supported: c_in 64 with normalisation (residual 0/1), c_in 32 without either (the stem). */
 int az_nn_conv_block(const void *x, int c_in, const void *weight_ohwi, const void *bias, const void *gamma,
-                     const void *beta, int residual, void *y, int64_t batch, float eps, void *stream);
+                     const void *beta, int residual, void *y, int64_t batch, float eps, const int64_t *batch_dev,
+                     void *stream);
 /* The whole gated attention block as a single MFMA kernel (nn_attn.hip):
  *   y = x + o_proj(sigmoid(gate) * softmax(qnorm(Q) knorm(K)^T / 4) V),  [Q|K|V|gate] = qkvg(RMSNorm(x))
  * (Network.py:51-93).  x, y (batch, 42, 64); qkvg_w (196, 64) row-major [out][in] with rows
  * 0-63 Q, 64-127 K, 128-191 V, 192-195 gate; o_w (64, 64) [out][in]; 4 heads of 16. */
 int az_nn_attn_block(const void *x, const void *prenorm_w, const void *qkvg_w, const void *q_norm_w,
-                     const void *k_norm_w, const void *o_w, void *y, int64_t batch, float eps, void *stream);
+                     const void *k_norm_w, const void *o_w, void *y, int64_t batch, float eps, const int64_t *batch_dev,
+                     void *stream);
 /* timing experiments on az_nn_conv_block: bit 0 skips its MFMA phase, bit 1 its epilogue and
  * stores, bit 4 records per-wavefront cycle totals of its phases (az_nn_conv_profile: 8 values
  * per wavefront - P1, barrier, MFMA + epilogue, staging wait, barrier, store - for the first
@@ -80,7 +90,8 @@ typedef struct az_nn_heads_weights {
     float p_gate_b, p_out_b, d_aux_b, aux_scale;
 } az_nn_heads_weights;
 int az_nn_heads(const void *tokens, const az_nn_heads_weights *w, const uint8_t *mask, float *probs, float *wdl,
-                float *moves_left, int64_t batch, float eps, void *stream);
+                float *moves_left, int64_t batch, float eps, const int32_t *scatter, const int64_t *batch_dev,
+                void *stream);
 
 #ifdef __cplusplus
 }

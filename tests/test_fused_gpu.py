@@ -173,7 +173,7 @@ def test_glue_kernels_match_torch(env):
     feats = (torch.rand(B, 3, 6, 7, device="cuda", generator=g) > 0.6).float()
     eo, ep, pos = rnd(32).to(bf), rnd(32).to(bf), rnd(42, 32).to(bf)
     tok = torch.empty(B, 42, 32, dtype=bf, device="cuda")
-    L.az_nn_embed(feats.data_ptr(), eo.data_ptr(), ep.data_ptr(), pos.data_ptr(), tok.data_ptr(), B, 32, s)
+    L.az_nn_embed(feats.data_ptr(), eo.data_ptr(), ep.data_ptr(), pos.data_ptr(), tok.data_ptr(), B, 32, None, None, s)
     want = pos.float() + feats[:, 0].reshape(B, 42, 1) * eo.float() + feats[:, 1].reshape(B, 42, 1) * ep.float()
     close(tok, want)
     # groupnorm1 + affine
@@ -242,7 +242,7 @@ def test_mfma_conv_block_matches_torch(env):
             y = torch.full((B, 42, 64), float("nan"), device="cuda").to(bf)
             rc = L.az_nn_conv_block(x.data_ptr(), cin, w_ohwi.data_ptr(), bias.data_ptr(),
                                     ga.data_ptr() if norm else None, be.data_ptr() if norm else None,
-                                    1 if resid else 0, y.data_ptr(), B, 1e-5, s)
+                                    1 if resid else 0, y.data_ptr(), B, 1e-5, None, s)
             assert rc == 0
             img = x.float().view(B, 6, 7, cin).permute(0, 3, 1, 2)
             h = TF.group_norm(img, 1, ga.float(), be.float(), 1e-5).to(bf).float() if norm else img
@@ -274,7 +274,7 @@ def test_mfma_attention_block_matches_torch(env):
         x = (rnd(B, 42, 64) * 1.2).to(bf)
         y = torch.full_like(x, float("nan"))
         assert L.az_nn_attn_block(x.data_ptr(), pre.data_ptr(), wqkvg.data_ptr(), qn.data_ptr(), kn.data_ptr(),
-                                  wo.data_ptr(), y.data_ptr(), B, 1e-5, s) == 0
+                                  wo.data_ptr(), y.data_ptr(), B, 1e-5, None, s) == 0
         xf = x.float()
         h = TF.rms_norm(xf, (64,), pre.float(), 1e-5).to(bf).float()
         proj = h @ wqkvg.float().t()
@@ -316,7 +316,7 @@ def test_fused_heads_kernel_matches_torch_heads(env):
         ml = torch.empty((B,), dtype=torch.float32, device="cuda")
         m8 = mask.to(torch.uint8).contiguous()
         assert L.az_nn_heads(tok.data_ptr(), C.byref(fast._heads_w), m8.data_ptr(), probs.data_ptr(), wdl.data_ptr(),
-                             ml.data_ptr(), B, 1e-5, s) == 0
+                             ml.data_ptr(), B, 1e-5, None, None, s) == 0
         torch.cuda.synchronize()
         assert torch.isfinite(probs).all() and torch.isfinite(wdl).all() and torch.isfinite(ml).all()
         assert (probs[~mask] == 0).all()
@@ -327,7 +327,7 @@ def test_fused_heads_kernel_matches_torch_heads(env):
         assert em.max().item() < 0.5, (B, em.max().item())
     # no mask = every column legal
     assert L.az_nn_heads(tok.data_ptr(), C.byref(fast._heads_w), None, probs.data_ptr(), wdl.data_ptr(),
-                         ml.data_ptr(), B, 1e-5, s) == 0
+                         ml.data_ptr(), B, 1e-5, None, None, s) == 0
     lp, _, _ = fast._heads_hip(tok, None, B, L, s)
     torch.cuda.synchronize()
     assert (probs - lp.exp()).abs().max().item() < 3e-2
@@ -370,6 +370,48 @@ def test_fused_with_network_statistical_agreement(env):
     assert (c1.sum(1) == 199).all() and (c2.sum(1) == 199).all()
     assert np.abs(s1[:, 1] - s2[:, 1]).mean() < 0.05          # root Q
     assert (np.argmax(c1, 1) == np.argmax(c2, 1)).mean() > 0.8
+
+
+def test_device_transposition_table_leaves_the_search_unchanged(env):
+    """SURVEY 8f row f2.  The evaluator kernels compute each row independently of its batch, so a
+    cached output is bit-identical to a fresh one and the search must not change at all: same
+    visit counts and root statistics with and without the table, zero mismatches in verify mode
+    (every leaf evaluated densely as well and compared with what the table path produced), and a
+    second search from the same roots is served almost entirely from the table."""
+    torch = env["torch"]
+    wts = load("g7_checkpoint_weights")
+    net = env["N"].Connect4Net(device="cuda").eval()
+    env["N"].load_reference_weights(net, {k: wts[k] for k in wts.files})
+    rng = np.random.default_rng(9)
+    boards, turns = S.random_openings(rng, 256, 9)
+    boards[:64] = boards[0]; turns[:64] = turns[0]            # many trees on one position: transpositions across trees
+    res = []
+    for table in (False, True):
+        w = env["W"].BatchedMCTS(256, 1.4, 400, 0.0, 80, noise_epsilon=0.25, fpu_reduction=0.2,
+                                 use_symmetry=True, mlh_slope=0.1)
+        w.seed(7)
+        fs = w._fused_runner(net, True)
+        if table:
+            fs.enable_table(12, verify=True)                  # 4096 entries: replacement happens too
+        w.batch_playout(net, boards, turns, vl_batch=4, fused=True)
+        res.append((w.get_visits_count().copy(), np.array(w.mcts.get_all_root_stats()).copy()))
+        if table:
+            st = fs.table_stats()
+            assert st["mismatches"] == 0 and st["hits"] > 0 and st["lookups"] >= st["hits"] + st["inserts"] - 1
+            assert st["replaced"] > 0
+            first = st
+            # the same roots again from fresh trees: nearly everything is known (capacity permitting)
+            fs.enable_table(18, verify=True)
+            for rep in range(2):
+                for i in range(256):
+                    w.mcts.reset_env(i)
+                w.batch_playout(net, boards, turns, vl_batch=4, fused=True)
+                st = fs.table_stats()
+                assert st["mismatches"] == 0
+            assert st["hit_rate"] > 0.4, st
+    (c0, s0), (c1, s1) = res
+    assert np.array_equal(c0, c1)
+    assert np.array_equal(bits(s0), bits(s1))
 
 
 def test_device_generator_noise_and_symmetry(env):

@@ -38,21 +38,21 @@ mask = torch.ones(B, 7, dtype=torch.uint8, device=dev)
 
 
 def conv():
-    L.az_nn_conv_block(x.data_ptr(), 64, w.data_ptr(), b.data_ptr(), g.data_ptr(), be.data_ptr(), 1, y.data_ptr(), B, 1e-5, s)
+    L.az_nn_conv_block(x.data_ptr(), 64, w.data_ptr(), b.data_ptr(), g.data_ptr(), be.data_ptr(), 1, y.data_ptr(), B, 1e-5, None, s)
 
 
 def stem():
-    L.az_nn_conv_block(x32.data_ptr(), 32, w32.data_ptr(), b.data_ptr(), None, None, 0, y.data_ptr(), B, 1e-5, s)
+    L.az_nn_conv_block(x32.data_ptr(), 32, w32.data_ptr(), b.data_ptr(), None, None, 0, y.data_ptr(), B, 1e-5, None, s)
 
 
 def attn():
     L.az_nn_attn_block(x.data_ptr(), net.pre_w.data_ptr(), net.qkvg_w.data_ptr(), net.qn_w.data_ptr(),
-                       net.kn_w.data_ptr(), net.o_w.data_ptr(), y.data_ptr(), B, 1e-5, s)
+                       net.kn_w.data_ptr(), net.o_w.data_ptr(), y.data_ptr(), B, 1e-5, None, s)
 
 
 def heads():
     L.az_nn_heads(x.data_ptr(), C.byref(net._heads_w), mask.data_ptr(), probs.data_ptr(), wdl.data_ptr(), ml.data_ptr(),
-                  B, 1e-5, s)
+                  B, 1e-5, None, None, s)
 
 
 KERNELS = {"conv": conv, "stem": stem, "attn": attn, "heads": heads}
