@@ -140,6 +140,7 @@ class BatchedMCTS:
         self._custom_converter = board_converter is not None
         self._convert_board = board_converter or _default_convert_board
         self.cache = LRUCache(cache_size) if cache_size > 0 else None
+        self._cache_size = int(cache_size)
         self._game_name = game_name
         self._rollout_eval = None
         self._fused = None
@@ -234,8 +235,12 @@ class BatchedMCTS:
     # ------------------------------------------------------------------ search
     def _fused_runner(self, pv_func, fused):
         """The device-resident loop applies when the evaluator is a torch module on the GPU and
-        nothing forces the host contract (custom features, transposition cache)."""
-        if fused is False or self.cache is not None or self._custom_converter:
+        nothing forces the host contract (custom features; the LRU transposition cache, unless
+        the caller passes fused=True, which moves the cache into a device table of at least
+        `cache_size` entries - include/az_mcts.h)."""
+        if fused is False or self._custom_converter:
+            return None
+        if self.cache is not None and fused is not True:
             return None
         try:
             from src import fused as _fused
@@ -249,6 +254,9 @@ class BatchedMCTS:
             return None
         if self._fused is None or self._fused.net is not pv_func:
             self._fused = _fused.FusedSearch(self, pv_func)
+            if self.cache is not None:
+                want = max(self._cache_size, 4)
+                self._fused.enable_table(min(max((want - 1).bit_length(), 10), 26))
         return self._fused
 
     def batch_playout(self, pv_func, current_boards, turns, n_playout=None,
@@ -309,7 +317,12 @@ class BatchedMCTS:
     run = batch_playout   # alias named in BASELINE.json's north_star ("MCTSBatch.run")
 
     def refresh_cache(self, pv_func):
-        """Re-evaluate every cached position after a weight update (MCTS_cpp.py:361-377)."""
+        """Re-evaluate every cached position after a weight update (MCTS_cpp.py:361-377).  The
+        device table of the fused path is emptied instead: its entries are re-evaluated when the
+        search meets them again."""
+        if self._fused is not None and self._fused.table_log2:
+            from src import fused as _fused
+            _fused.check(_fused.lib().az_mcts_dev_tt_clear(self._fused.h, _fused._stream()))
         if self.cache is None or len(self.cache) == 0:
             return self
         if hasattr(pv_func, 'score_scale'):

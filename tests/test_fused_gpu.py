@@ -412,6 +412,14 @@ def test_device_transposition_table_leaves_the_search_unchanged(env):
     (c0, s0), (c1, s1) = res
     assert np.array_equal(c0, c1)
     assert np.array_equal(bits(s0), bits(s1))
+    # the wrapper's cache_size reaches the device table when the caller asks for the fused path
+    w = env["W"].BatchedMCTS(256, 1.4, 400, 0.0, 80, noise_epsilon=0.25, fpu_reduction=0.2, use_symmetry=True,
+                             mlh_slope=0.1, cache_size=3000)
+    w.seed(7)
+    w.batch_playout(net, boards, turns, vl_batch=4, fused=True)
+    assert w._fused is not None and w._fused.table_log2 == 12 and w._fused.table_stats()["hits"] > 0
+    assert np.array_equal(w.get_visits_count(), c0)
+    w.refresh_cache(net)
 
 
 def test_device_generator_noise_and_symmetry(env):
