@@ -227,7 +227,6 @@ class DeviceSelfPlay:
         slots = self.fin_slot[:n].cpu().numpy()
         self.n_finished.zero_()
         games = []
-        zero_wdl = np.zeros(3, dtype=np.float32)
         k = self.td_steps
         for g in range(n):
             T = int(lens[g])
@@ -236,11 +235,16 @@ class DeviceSelfPlay:
             winner_z = np.full(T, winner, dtype=np.int32)
             steps_to_end = np.arange(T, 0, -1, dtype=np.int32)
             aux = steps_to_end                                       # game.py:17-23, Connect4: moves left
-            probs, wdls, masks = host["prob"][g], host["wdl"][g], host["mask"][g]
-            cols = [list(states[:T]), [probs[t] for t in range(T)], list(winner_z), list(steps_to_end), list(aux),
-                    [wdls[t] for t in range(T)], [masks[t] for t in range(T)]]
+            probs, masks = host["prob"][g], host["mask"][g]
+            # object identities as in game.py:121-157 (one root-WDL object per ply, reused by the
+            # td-step column; one zero vector per game): pickle writes shared objects once, so
+            # the upload below is byte-identical to the reference client's only if they match
+            root_wdls = [host["wdl"][g][t] for t in range(T)]
+            zero_wdl = np.zeros(3, dtype=np.float32)
+            cols = [[states[t] for t in range(T)], [probs[t] for t in range(T)], winner_z, steps_to_end, aux,
+                    root_wdls, [masks[t] for t in range(T)]]
             if k > 0:
-                cols.append([wdls[t + k] if t + k < T else zero_wdl for t in range(T)])
+                cols.append([root_wdls[t + k] if t + k < T else zero_wdl for t in range(T)])
             play = list(zip(*cols))
             terminal = [states[T], np.zeros_like(probs[0]), winner, 0, 0, zero_wdl, np.ones_like(masks[0])]
             if k > 0:
@@ -255,6 +259,14 @@ class DeviceSelfPlay:
 
     def engine_counters(self):
         return F.counters(self.h)
+
+
+def pack_upload(games):
+    """The body of the actor's POST /upload for these games (client.py:366-368 with 386-388):
+    pickle of {'__az__': True, 'data': [play_data, ...]} at the highest protocol.  `games` is
+    what `DeviceSelfPlay.drain()` (or the reference's `batch_self_play`) returned."""
+    import pickle
+    return pickle.dumps({'__az__': True, 'data': [g[1] for g in games]}, protocol=pickle.HIGHEST_PROTOCOL)
 
 
 def planes_from_bitboards(bb_p1, bb_p2, turn):

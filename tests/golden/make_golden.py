@@ -277,6 +277,12 @@ def gen_g10():
         out[f"g{i}_winner"] = np.array([winner], np.int32)
         for j, nm in enumerate(("state", "prob", "z", "steps", "aux", "root_wdl", "mask", "fut")):
             out[f"g{i}_{nm}"] = np.array([np.asarray(tup[j]) for tup in play])
+    # what client.py:366-368,386-388 would POST for these games
+    import pickle
+    payload = pickle.dumps({'__az__': True, 'data': [play for _, play in data]}, protocol=pickle.HIGHEST_PROTOCOL)
+    out["upload_payload"] = np.frombuffer(payload, dtype=np.uint8)
+    out["upload_numpy_version"] = np.array([int(x) for x in np.__version__.split(".")[:2]], np.int32)
+    out["upload_python_version"] = np.array(sys.version_info[:2], np.int32)
     save("g10_selfplay_numpy_rng", **out)
 
 

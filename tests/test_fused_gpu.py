@@ -512,6 +512,23 @@ def test_device_selfplay_trajectories_equal_reference_harness_g10(env):
                 assert np.array_equal(bits(got), bits(ref)), (i, nm)
             else:
                 assert np.array_equal(got, ref), (i, nm)
+    # row f4: the actor's upload body for these games, byte for byte (same numpy / python as the
+    # generator; otherwise the pickles must at least decode to the same structure)
+    import pickle
+    import sys as _sys
+    from src.selfplay import pack_upload
+    mine = pack_upload(games)
+    ref_payload = g["upload_payload"].tobytes()
+    same_env = (list(g["upload_numpy_version"]) == [int(x) for x in np.__version__.split(".")[:2]]
+                and list(g["upload_python_version"]) == list(_sys.version_info[:2]))
+    if same_env:
+        assert mine == ref_payload
+    a, b = pickle.loads(mine), pickle.loads(ref_payload)
+    assert a["__az__"] is True and len(a["data"]) == len(b["data"]) == 16
+    for pa, pb in zip(a["data"], b["data"]):
+        assert len(pa) == len(pb)
+        for ta, tb in zip(pa, pb):
+            assert len(ta) == len(tb) and all(type(x) is type(y) and np.array_equal(x, y) for x, y in zip(ta, tb))
 
 
 def test_device_selfplay_recording_with_refill(env):
