@@ -100,6 +100,9 @@ struct EventRing {
     bool begin(hipStream_t s)
     {
         if (used >= start.size()) return false;
+        // an event recorded into a graph under capture has no timestamp to read back
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone) return false;
         HIP_OK(hipEventRecord(start[used], s));
         return true;
     }
