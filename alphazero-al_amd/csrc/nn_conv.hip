@@ -138,11 +138,21 @@ __device__ __forceinline__ void lds_barrier()
 // az_nn_debug bit 4: per-wave cycle totals of the phases (s_memtime), read back by az_nn_conv_profile
 __device__ unsigned long long g_prof[2048 * 8];
 
-template <int CIN, bool NORM, bool RESID>
+// what the stem needs to build its input tokens itself (EMBED): the evaluator's feature planes and
+// the embedding tables of Network.py:226-239
+struct EmbedIn {
+    const float    *features;          // (rows, 3, 6, 7) relative planes
+    const uint16_t *emb_own, *emb_opp; // (32,) bf16
+    const uint16_t *pos;               // (42, 32) bf16
+    const int32_t  *gather;            // compact sample b shows row gather[b] (NULL: b)
+};
+
+template <int CIN, bool NORM, bool RESID, bool EMBED = false>
 __global__ void __launch_bounds__(256, 2) k_conv_block(const uint16_t *x, const uint16_t *w, const uint16_t *bias,
                                                        const uint16_t *gamma, const uint16_t *beta, uint16_t *y,
-                                                       int64_t B, float eps, int dbg, const int64_t *batch_dev)
+                                                       int64_t B, float eps, int dbg, const int64_t *batch_dev, EmbedIn em)
 {
+    static_assert(!EMBED || (CIN == 32 && !NORM && !RESID), "the embedding is fused into the stem only");
     if (batch_dev != nullptr && *batch_dev < B) B = *batch_dev;       // compact batch whose size only the device knows
     constexpr int K = 9 * CIN;
     constexpr int KSTEPS = K / 32;                // 18 (C_in 64) or 9 (C_in 32)
@@ -207,9 +217,14 @@ __global__ void __launch_bounds__(256, 2) k_conv_block(const uint16_t *x, const 
     // lane with one fixed channel chunk in P1.
     auto swz_in = [](int cell) { return VPC == 8 ? (cell & 7) : 0; };
     const uint32_t raw_lds = lds_addr(rawb);
+    if (EMBED) {                                   // the raw buffers are free: the position table lives there
+        for (int i = tid; i < CELLS * CIN / 8; i += 256)
+            reinterpret_cast<V8 *>(rawb)[i] = reinterpret_cast<const V8 *>(em.pos)[i];
+        __syncthreads();
+    }
     auto stage_tile = [&](int64_t tile, int buf, int lane) {
         const int64_t b = tile * TS + wave;
-        if (b >= B) return;
+        if (EMBED || b >= B) return;
         const uint16_t *xs = x + b * (CELLS * CIN);
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
@@ -222,6 +237,22 @@ __global__ void __launch_bounds__(256, 2) k_conv_block(const uint16_t *x, const 
     };
 
     const int64_t ntiles = (B + TS - 1) / TS;
+    // EMBED: the two planes of this wave's sample at this lane's cells, one tile ahead
+    float pl_own[PER], pl_opp[PER];
+    auto load_planes = [&](int64_t tile, int lane) {
+        const int64_t b = tile * TS + wave;
+        const bool live = b < B;
+        const int64_t row = !live ? 0 : (em.gather != nullptr ? em.gather[b] : b);
+        const float *fs = em.features + row * (3 * CELLS);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int s = lane + 64 * i;
+            const bool ok = live && s < VPS;
+            pl_own[i] = ok ? fs[s / VPC] : 0.0f;
+            pl_opp[i] = ok ? fs[CELLS + s / VPC] : 0.0f;
+        }
+    };
+    if (EMBED && static_cast<int64_t>(blockIdx.x) < ntiles) load_planes(blockIdx.x, lane);
     if (static_cast<int64_t>(blockIdx.x) < ntiles) stage_tile(blockIdx.x, 0, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
@@ -250,11 +281,33 @@ __global__ void __launch_bounds__(256, 2) k_conv_block(const uint16_t *x, const 
         {
             const int ck = (lane_t % VPC) ^ swz_in(lane_t / VPC);   // the channel chunk of every slot this lane owns
             V8 raw[PER];
+            if (EMBED) {
+                // tokens = pos[cell] + own * emb_own + opp * emb_opp (fp32 on the bf16 tables, rounded once:
+                // the arithmetic of k_embed, nn_kernels.hip)
+                const V8 eo = *reinterpret_cast<const V8 *>(em.emb_own + ck * 8), ep = *reinterpret_cast<const V8 *>(em.emb_opp + ck * 8);
 #pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                const int s = lane_t + 64 * i;
-                if (s < VPS) raw[i] = *reinterpret_cast<const V8 *>(rawt + wave * SB + s * 16);
-                else raw[i].w[0] = raw[i].w[1] = raw[i].w[2] = raw[i].w[3] = 0;
+                for (int i = 0; i < PER; ++i) {
+                    const int s = lane_t + 64 * i;
+                    if (s < VPS) {
+                        const V8 ps = *reinterpret_cast<const V8 *>(rawb + s * 16);
+                        const f32x2 own = {pl_own[i], pl_own[i]}, opp = {pl_opp[i], pl_opp[i]};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            // p + own*a + opp*o evaluated left to right, as k_embed does
+                            const f32x2 v = unpack2(ps.w[q]) + own * unpack2(eo.w[q]) + opp * unpack2(ep.w[q]);
+                            raw[i].w[q] = pack2(v.x, v.y);
+                        }
+                    } else {
+                        raw[i].w[0] = raw[i].w[1] = raw[i].w[2] = raw[i].w[3] = 0;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < PER; ++i) {
+                    const int s = lane_t + 64 * i;
+                    if (s < VPS) raw[i] = *reinterpret_cast<const V8 *>(rawt + wave * SB + s * 16);
+                    else raw[i].w[0] = raw[i].w[1] = raw[i].w[2] = raw[i].w[3] = 0;
+                }
             }
             f32x2 sc[4], sh[4];
             if (NORM) {
@@ -304,7 +357,10 @@ __global__ void __launch_bounds__(256, 2) k_conv_block(const uint16_t *x, const 
         stamp(1);
         // the next tile travels from HBM into the other raw buffer while this one is multiplied
         // (every wave finished reading that buffer - P3 of the previous tile - before the barrier)
-        if (tile + gridDim.x < ntiles) stage_tile(tile + gridDim.x, par ^ 1, lane_t);
+        if (tile + gridDim.x < ntiles) {
+            stage_tile(tile + gridDim.x, par ^ 1, lane_t);
+            if (EMBED) load_planes(tile + gridDim.x, lane_t);
+        }
 
         // ---- P2: wave (mh, th) owns samples 2*th and 2*th+1 of the tile, each as three token
         // tiles of 16 over a 6 x 8 token grid: token t sits at image cell t + 9, its 8th column is
@@ -446,14 +502,14 @@ __global__ void __launch_bounds__(256, 2) k_conv_block(const uint16_t *x, const 
 
 int g_dbg = 0;   // timing experiments only (az_nn_debug): 1 skips the MFMA loop, 2 skips the store
 
-template <int CIN, bool NORM, bool RESID>
+template <int CIN, bool NORM, bool RESID, bool EMBED = false>
 int launch(const void *x, const void *w, const void *bias, const void *gamma, const void *beta, void *y, int64_t B,
-           float eps, const int64_t *batch_dev, hipStream_t s)
+           float eps, const int64_t *batch_dev, hipStream_t s, EmbedIn em = EmbedIn{})
 {
     constexpr size_t smem = static_cast<size_t>(TS) * PCELLS * CELLB + 2 * static_cast<size_t>(TS) * CELLS * CIN * 2 +
                             (RESID ? 0 : static_cast<size_t>(TS) * CELLS * COUT * 2) + 2 * CIN * sizeof(float) + 512;
     static bool attr_set = false;
-    auto kern = k_conv_block<CIN, NORM, RESID>;
+    auto kern = k_conv_block<CIN, NORM, RESID, EMBED>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 static_cast<int>(smem)) != hipSuccess)
@@ -471,7 +527,7 @@ int launch(const void *x, const void *w, const void *bias, const void *gamma, co
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, static_cast<const uint16_t *>(x),
                        static_cast<const uint16_t *>(w), static_cast<const uint16_t *>(bias),
                        static_cast<const uint16_t *>(gamma), static_cast<const uint16_t *>(beta),
-                       static_cast<uint16_t *>(y), B, eps, g_dbg, batch_dev);
+                       static_cast<uint16_t *>(y), B, eps, g_dbg, batch_dev, em);
     return 0;
 }
 
@@ -498,6 +554,17 @@ int az_nn_conv_block(const void *x, int c_in, const void *weight_ohwi, const voi
     if (c_in == 64 && norm && !residual) return launch<64, true, false>(x, weight_ohwi, bias, gamma, beta, y, batch, eps, batch_dev, s);
     if (c_in == 32 && !norm && !residual) return launch<32, false, false>(x, weight_ohwi, bias, gamma, beta, y, batch, eps, batch_dev, s);
     return 1;
+}
+
+int az_nn_stem_embed(const float *features, const void *emb_own, const void *emb_opp, const void *pos,
+                     const void *weight_ohwi, const void *bias, void *y, int64_t batch, const int32_t *gather,
+                     const int64_t *batch_dev, void *stream)
+{
+    if (batch <= 0 || features == nullptr) return 1;
+    EmbedIn em{features, static_cast<const uint16_t *>(emb_own), static_cast<const uint16_t *>(emb_opp),
+               static_cast<const uint16_t *>(pos), gather};
+    return launch<32, false, false, true>(nullptr, weight_ohwi, bias, nullptr, nullptr, y, batch, 0.0f, batch_dev,
+                                          static_cast<hipStream_t>(stream), em);
 }
 
 }  // extern "C"

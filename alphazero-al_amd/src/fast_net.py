@@ -46,6 +46,7 @@ def glue():
             L.az_nn_conv_block.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, i64, f32, vp, vp]
             L.az_nn_attn_block.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, f32, vp, vp]
             L.az_nn_heads.argtypes = [vp, C.POINTER(HeadsWeights), vp, vp, vp, vp, i64, f32, vp, vp, vp]
+            L.az_nn_stem_embed.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp]
             _GLUE = L
         except OSError:
             _GLUE = False
@@ -128,6 +129,7 @@ class FastConnect4Net(torch.nn.Module):
                     and glue() is not None)
         self.mfma_conv = self.hip and os.environ.get("AZ_NN_MFMA_CONV", "1") != "0"
         self.mfma_attn = self.hip and os.environ.get("AZ_NN_MFMA_ATTN", "1") != "0"
+        self.fused_stem = self.mfma_conv and os.environ.get("AZ_NN_FUSED_STEM", "1") != "0"
         self.fused_heads = self.mfma_conv and self.mfma_attn and os.environ.get("AZ_NN_FUSED_HEADS", "1") != "0"
         self._heads_w = None
         if self.fused_heads:
@@ -234,12 +236,17 @@ class FastConnect4Net(torch.nn.Module):
         dev, bf = self.device, torch.bfloat16
         c_dim = self.h_dim
         x = x.contiguous().float()
-        t0 = torch.empty((bsz, CELLS, self.embed_dim), dtype=bf, device=dev)
-        L.az_nn_embed(x.data_ptr(), self.emb_own.data_ptr(), self.emb_opp.data_ptr(), self.pos.data_ptr(),
-                      t0.data_ptr(), bsz, self.embed_dim, gp, np_, s)
         t = torch.empty((bsz, CELLS, c_dim), dtype=bf, device=dev)
-        L.az_nn_conv_block(t0.data_ptr(), self.embed_dim, self.stem_w.data_ptr(), self.stem_b.data_ptr(), None,
-                           None, 0, t.data_ptr(), bsz, 1e-5, np_, s)
+        if self.fused_stem:
+            # embedding + stem convolution in one kernel: the tokens are built in LDS
+            L.az_nn_stem_embed(x.data_ptr(), self.emb_own.data_ptr(), self.emb_opp.data_ptr(), self.pos.data_ptr(),
+                               self.stem_w.data_ptr(), self.stem_b.data_ptr(), t.data_ptr(), bsz, gp, np_, s)
+        else:
+            t0 = torch.empty((bsz, CELLS, self.embed_dim), dtype=bf, device=dev)
+            L.az_nn_embed(x.data_ptr(), self.emb_own.data_ptr(), self.emb_opp.data_ptr(), self.pos.data_ptr(),
+                          t0.data_ptr(), bsz, self.embed_dim, gp, np_, s)
+            L.az_nn_conv_block(t0.data_ptr(), self.embed_dim, self.stem_w.data_ptr(), self.stem_b.data_ptr(), None,
+                               None, 0, t.data_ptr(), bsz, 1e-5, np_, s)
         for w, b, g, beta in self.res:
             t2 = torch.empty_like(t)
             L.az_nn_conv_block(t.data_ptr(), c_dim, getattr(self, w).data_ptr(), getattr(self, b).data_ptr(),

@@ -47,6 +47,11 @@ int az_nn_silu_add(const void *x, const void *bias, int channels, const void *re
 int az_nn_conv_block(const void *x, int c_in, const void *weight_ohwi, const void *bias, const void *gamma,
                      const void *beta, int residual, void *y, int64_t batch, float eps, const int64_t *batch_dev,
                      void *stream);
+/* The stem with the embedding fused in: az_nn_embed + az_nn_conv_block(c_in 32) as one kernel
+ * that builds its tokens from the feature planes (no (batch, 42, 32) tensor in HBM). */
+int az_nn_stem_embed(const float *features, const void *emb_own, const void *emb_opp, const void *pos,
+                     const void *weight_ohwi, const void *bias, void *y, int64_t batch, const int32_t *gather,
+                     const int64_t *batch_dev, void *stream);
 /* The whole gated attention block as a single MFMA kernel (nn_attn.hip):
  *   y = x + o_proj(sigmoid(gate) * softmax(qnorm(Q) knorm(K)^T / 4) V),  [Q|K|V|gate] = qkvg(RMSNorm(x))
  * (Network.py:51-93).  x, y (batch, 42, 64); qkvg_w (196, 64) row-major [out][in] with rows

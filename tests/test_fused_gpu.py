@@ -256,6 +256,35 @@ def test_mfma_conv_block_matches_torch(env):
             assert err.max().item() < 6e-2 and err.mean().item() < 4e-3, (B, cin, err.max().item(), err.mean().item())
 
 
+def test_stem_with_fused_embedding_equals_two_kernels(env):
+    """az_nn_stem_embed against az_nn_embed followed by the stem az_nn_conv_block: same arithmetic,
+    bit-identical output; also through a gather list (compact batch)."""
+    torch = env["torch"]
+    import ctypes as C
+    from src.fast_net import FastConnect4Net, glue
+    wts = load("g7_checkpoint_weights")
+    net = env["N"].Connect4Net(device="cuda").eval()
+    env["N"].load_reference_weights(net, {k: wts[k] for k in wts.files})
+    fast = FastConnect4Net.from_module(net)
+    L = glue()
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = load("g7_network")
+    planes = torch.from_numpy(_planes(g["boards"], g["turns"])).cuda().float().contiguous()
+    for B, gather in ((planes.shape[0], None), (100, torch.randperm(planes.shape[0], device="cuda")[:100].to(torch.int32))):
+        gp = None if gather is None else gather.data_ptr()
+        t0 = torch.empty((B, 42, 32), dtype=torch.bfloat16, device="cuda")
+        y0 = torch.empty((B, 42, 64), dtype=torch.bfloat16, device="cuda")
+        y1 = torch.empty_like(y0)
+        assert L.az_nn_embed(planes.data_ptr(), fast.emb_own.data_ptr(), fast.emb_opp.data_ptr(), fast.pos.data_ptr(),
+                             t0.data_ptr(), B, 32, gp, None, s) == 0
+        assert L.az_nn_conv_block(t0.data_ptr(), 32, fast.stem_w.data_ptr(), fast.stem_b.data_ptr(), None, None, 0,
+                                  y0.data_ptr(), B, 1e-5, None, s) == 0
+        assert L.az_nn_stem_embed(planes.data_ptr(), fast.emb_own.data_ptr(), fast.emb_opp.data_ptr(), fast.pos.data_ptr(),
+                                  fast.stem_w.data_ptr(), fast.stem_b.data_ptr(), y1.data_ptr(), B, gp, None, s) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+
+
 def test_mfma_attention_block_matches_torch(env):
     """nn_attn.hip (RMSNorm -> QKV+gate projection -> per-head RMSNorm -> softmax attention ->
     gate -> output projection + residual, all on MFMA in registers) against torch fp32."""

@@ -55,7 +55,16 @@ def heads():
                   B, 1e-5, None, None, s)
 
 
-KERNELS = {"conv": conv, "stem": stem, "attn": attn, "heads": heads}
+feat = (torch.rand(B, 3, 6, 7, device=dev) > 0.5).float()
+L.az_nn_stem_embed.argtypes = [C.c_void_p] * 7 + [C.c_int64] + [C.c_void_p] * 3
+
+
+def stem_embed():
+    L.az_nn_stem_embed(feat.data_ptr(), net.emb_own.data_ptr(), net.emb_opp.data_ptr(), net.pos.data_ptr(),
+                       w32.data_ptr(), b.data_ptr(), y.data_ptr(), B, None, None, s)
+
+
+KERNELS = {"conv": conv, "stem": stem, "stem_embed": stem_embed, "attn": attn, "heads": heads}
 
 
 def timed(fn, n=20):
@@ -94,5 +103,5 @@ else:
         print("   %-18s mean %9.0f cycles/wave (%4.1f%%)  min %9.0f max %9.0f" % (nm, ph[:, k].mean(), 100 * ph[:, k].mean() / tot, ph[:, k].min(), ph[:, k].max()))
     print("   total %9.0f cycles per wave (memtime ticks, 100 MHz?)" % tot)
     L.az_nn_debug(0)
-    for name in ("stem", "attn", "heads"):
+    for name in ("stem", "stem_embed", "attn", "heads"):
         print("%-27s %7.1f us" % (name, timed(KERNELS[name])))
