@@ -331,7 +331,7 @@ az_mcts *create_engine(int game, int n_envs, int device)
         m->root.ensure(n_envs); m->used.ensure(n_envs);
         m->r_bb0.ensure(n_envs, true); m->r_bb1.ensure(n_envs, true);
         m->r_turn.ensure(n_envs, true); m->r_last.ensure(n_envs, true);
-        m->counters.ensure(az::CNT_N, true);
+        m->counters.ensure(az::CNT_N * az::CNT_STRIPES, true);
         m->err.ensure(1, true);
         m->call_ctr.ensure(1, true);
         m->plain_leaf.ensure(n_envs);
@@ -937,10 +937,14 @@ int az_mcts_counters(az_mcts *m, int64_t out[AZ_NUM_COUNTERS])
 {
     return guarded([&] {
         HIP_OK(hipSetDevice(m->device));
-        unsigned long long h[az::CNT_N];
+        unsigned long long h[az::CNT_N * az::CNT_STRIPES];
         HIP_OK(hipDeviceSynchronize());
         HIP_OK(hipMemcpy(h, m->counters.p, sizeof h, hipMemcpyDeviceToHost));
-        for (int i = 0; i < az::CNT_N; ++i) out[i] = static_cast<int64_t>(h[i]);
+        for (int i = 0; i < az::CNT_N; ++i) {
+            unsigned long long sum = 0;
+            for (int st = 0; st < az::CNT_STRIPES; ++st) sum += h[st * az::CNT_N + i];
+            out[i] = static_cast<int64_t>(sum);
+        }
         out[az::CNT_SELECT_LAUNCHES] = m->select_launches;
         out[az::CNT_BACKPROP_LAUNCHES] = m->backprop_launches;
         m->check_device_error();
@@ -952,7 +956,7 @@ int az_mcts_counters_reset(az_mcts *m)
     return guarded([&] {
         HIP_OK(hipSetDevice(m->device));
         HIP_OK(hipDeviceSynchronize());
-        HIP_OK(hipMemset(m->counters.p, 0, sizeof(unsigned long long) * az::CNT_N));
+        HIP_OK(hipMemset(m->counters.p, 0, sizeof(unsigned long long) * az::CNT_N * az::CNT_STRIPES));
         m->select_launches = m->backprop_launches = 0;
     });
 }

@@ -93,6 +93,8 @@ struct TtTable {
 
 enum : int { CNT_SIMS = 0, CNT_LEVELS, CNT_EXPANSIONS, CNT_TERMINAL, CNT_DUP, CNT_BACKUP,
              CNT_SELECT_LAUNCHES, CNT_BACKPROP_LAUNCHES, CNT_N };
+constexpr int CNT_STRIPES = 64;      // striped copies of the counters (CNT_N * 8 B = one 64-byte line each)
+static_assert(CNT_N == 8, "one counter stripe is one 64-byte line");
 
 // Every launcher takes the game id (AZ_GAME_*) and dispatches to the kernel instantiation.
 void launch_import(int game, const int8_t *boards, const int32_t *turns, RootState rs, int B, hipStream_t s);

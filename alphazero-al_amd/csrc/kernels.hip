@@ -87,10 +87,14 @@ struct DevRng {
     }
 };
 
+// Work counters: CNT_STRIPES copies of the CNT_N counters, one 64-byte line each; a workgroup
+// adds to the copy picked by its index, the host sums the copies.  A single copy made a thousand
+// wavefronts queue on three L2 atomics per launch.
 __device__ __forceinline__ void wave_add_counter(unsigned long long *counters, int which, unsigned v)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, WAVE);
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&counters[which], static_cast<unsigned long long>(v));
+    if ((threadIdx.x & 63) == 0 && v)
+        atomicAdd(&counters[(blockIdx.x % CNT_STRIPES) * CNT_N + which], static_cast<unsigned long long>(v));
 }
 
 template <int L>
@@ -512,6 +516,242 @@ __global__ void __launch_bounds__(WAVE) k_backprop(TreeArena ar, LeafBuf lf, Sea
     wave_add_counter(counters, CNT_BACKUP, n_backup);
 }
 
+// The same call for K <= KMAX with the dependent memory round trips taken out.  k_backprop walks
+// k = 0..K-1 and, for each, loads the leaf, then its record, then its path, then the path's
+// records, updates and stores them - about four dependent HBM round trips per k, sixteen per
+// launch, which is what the kernel's 50 us were made of (90 % of its wave cycles in s_waitcnt).
+// Here everything any k needs is fetched up front in two rounds (leaf descriptors and path slots;
+// then the records), the K updates happen in registers in the reference's order - a node that
+// several paths share (the root always, duplicates of a leaf) is found by comparing slots at the
+// lane that owns its depth and is accumulated once per k in ascending k, the order of the
+// reference's sequential read-modify-writes, so the float sums are bit-identical - and every
+// distinct node is written back once.  Depths beyond the first LANES levels (rare) take the
+// sequential route of k_backprop.
+template <class G, bool VL, bool FUSED, int KMAX>
+__global__ void __launch_bounds__(WAVE) k_backprop_batched(TreeArena ar, LeafBuf lf, SearchParams p, int K, int tpw,
+                                                           EvalIn in, unsigned long long *counters, int *err)
+{
+    constexpr int L = G::LANES;
+    constexpr int A = G::ACTIONS;
+    const int lane = threadIdx.x;
+    const int sub = lane % L;
+    const int grp = lane / L;
+    const int tree = blockIdx.x * tpw + grp;
+    const bool live = grp < tpw && tree < ar.B;
+    const int t = live ? tree : 0;
+    HotRec *hot = ar.hot + static_cast<size_t>(t) * ar.S;
+    ColdRec *cold = ar.cold + static_cast<size_t>(t) * ar.S;
+    const size_t flat0 = static_cast<size_t>(t) * K;
+    unsigned n_exp = 0, n_dup = 0, n_backup = 0;
+
+    if (live) {
+        // ---- round 1: what selection left behind for every k, and this lane's path slot
+        int len[KMAX], leaf[KMAX], pslot[KMAX], sym[KMAX];
+        uint8_t lflags[KMAX];
+        GameState ls[KMAX];
+        float ev_d[KMAX], ev_w[KMAX], ev_l[KMAX], ev_ml[KMAX];
+        int used = ar.used[t];
+        const int used0 = used;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const bool on = k < K;
+            const size_t flat = flat0 + (on ? k : 0);
+            len[k] = on ? lf.path_len[flat] : 0;
+            leaf[k] = lf.slot[flat];
+            lflags[k] = lf.flags[flat];
+            ls[k].bb0 = lf.bb0[flat]; ls[k].bb1 = lf.bb1[flat]; ls[k].turn = lf.turn[flat]; ls[k].aux = lf.aux[flat];
+            sym[k] = in.sym ? in.sym[flat] : lf.sym[flat];
+            pslot[k] = lf.path[flat * G::MAX_PATH + sub];            // garbage past the path's end: masked by len
+            if (FUSED) {
+                ev_d[k] = in.wdl_rel[flat * 3]; ev_w[k] = in.wdl_rel[flat * 3 + 1]; ev_l[k] = in.wdl_rel[flat * 3 + 2];
+            } else {
+                ev_d[k] = in.d[flat]; ev_w[k] = in.p1w[flat]; ev_l[k] = in.p2w[flat];
+            }
+            ev_ml[k] = in.moves_left[flat];
+        }
+        // ---- round 2: the records (this lane's node of every path, every leaf's flags) and the
+        // policy entry of this lane's move
+        bool mine[KMAX];
+        HotRec rec[KMAX];
+        float cdraw[KMAX], my_pol[KMAX];
+        uint32_t leaf_meta[KMAX];
+        int nv[KMAX], my_action[KMAX];
+        bool is_term_host[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            mine[k] = sub < len[k];
+            const int slot = mine[k] ? pslot[k] : 0;
+            rec[k] = hot[slot];
+            cdraw[k] = cold[slot].w_draw;
+            leaf_meta[k] = len[k] > 0 ? hot[leaf[k]].meta : 0u;
+            nv[k] = G::num_valid(ls[k]);
+            my_action[k] = sub < nv[k] ? G::nth_valid(ls[k], sub) : -1;
+            const size_t flat = flat0 + (k < K ? k : 0);
+            my_pol[k] = my_action[k] >= 0 ? in.policy[flat * A + G::policy_index(sym[k], my_action[k])] : 0.0f;
+            is_term_host[k] = FUSED ? false : in.is_term[flat] != 0;
+        }
+
+        // ---- virtual loss comes off every node of every recorded path (MCTS.h:561-581)
+        int first[KMAX];                                            // earliest k whose node at this depth is the same record
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            first[k] = k;
+#pragma unroll
+            for (int q = KMAX - 1; q >= 0; --q)
+                if (q < k && mine[q] && mine[k] && pslot[q] == pslot[k]) first[k] = q;
+        }
+        if (VL) {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                if (len[k] > 0 && (lflags[k] & LEAF_VL_APPLIED)) {
+#pragma unroll
+                    for (int q = 0; q < KMAX; ++q)
+                        if (mine[k] && first[k] == q) rec[q].n_inflight -= p.vl_count;
+                    for (int j = sub + L; j < len[k]; j += L) hot[lf.path[(flat0 + k) * G::MAX_PATH + j]].n_inflight -= p.vl_count;
+                    if (sub == 0) lf.flags[flat0 + k] = lflags[k] & static_cast<uint8_t>(~LEAF_VL_APPLIED);
+                }
+            }
+        }
+
+        // ---- k = 0..K-1 in order: expansion (MCTS.h:329-375), then the backup of that leaf
+        bool expanded_here[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            expanded_here[k] = false;
+            if (len[k] <= 0) continue;                              // MCTS.h:409,599
+            const size_t flat = flat0 + k;
+            const int owner = (len[k] - 1) % L;
+            bool term;
+            float wd, w1, w2, ml;
+            if (FUSED) {
+                term = (lflags[k] & LEAF_TERMINAL) != 0;
+                if (term) {                                         // MCTS_cpp.py:275-282
+                    const int code = (lflags[k] >> LEAF_RESULT_SHIFT) & 3;
+                    wd = code == 0 ? 1.0f : 0.0f; w1 = code == 1 ? 1.0f : 0.0f; w2 = code == 2 ? 1.0f : 0.0f;
+                    ml = 0.0f;
+                } else {                                            // MCTS_cpp.py:23-30
+                    wd = ev_d[k];
+                    w1 = (ls[k].turn == 1) ? ev_w[k] : ev_l[k];
+                    w2 = (ls[k].turn == 1) ? ev_l[k] : ev_w[k];
+                    ml = ev_ml[k];
+                }
+            } else {
+                term = is_term_host[k];
+                wd = ev_d[k]; w1 = ev_w[k]; w2 = ev_l[k];
+                ml = ev_ml[k];
+            }
+            if (term) ml = G::terminal_aux(ls[k], p);               // MCTS.h:412,608
+
+            if (!term) {
+                // already expanded: before this call, or by an earlier k of it (MCTS.h:601-607)
+                bool was = (leaf_meta[k] & META_EXPANDED) != 0;
+#pragma unroll
+                for (int q = 0; q < KMAX; ++q)
+                    if (q < k && expanded_here[q] && leaf[q] == leaf[k]) was = true;
+                if (VL && was) {
+                    ++n_dup;
+                } else {
+                    float psum = 0.0f;
+                    if (L <= 8) {
+#pragma unroll
+                        for (int i = 0; i < L - 1; ++i) psum += __shfl(my_pol[k], i, L);
+                    } else {
+                        for (int i = 0; i < nv[k]; ++i) psum += __shfl(my_pol[k], i, L);
+                    }
+                    const float prior = my_pol[k] / (psum + 1e-8f);  // MCTS.h:370
+                    if (static_cast<int64_t>(used) + nv[k] > ar.S) {
+                        if (sub == 0) atomicExch(err, 1);
+                    } else {
+                        const bool root_leaf = (len[k] == 1);       // leaf.parent == -1, MCTS.h:349
+                        float noise = 0.0f;
+                        if (root_leaf && p.alpha > 0.0f && sub < nv[k]) {
+                            if (in.root_noise) {
+                                noise = in.root_noise[static_cast<size_t>(t) * A + sub];
+                            } else {
+                                DevRng g(p.seed, *p.call_ptr, static_cast<uint64_t>(t), static_cast<uint64_t>(sub) + 16);
+                                noise = g.gamma(p.alpha);
+                            }
+                        }
+                        if (root_leaf && p.alpha > 0.0f && !in.root_noise) {
+                            float sum = 0.0f;
+                            for (int i = 0; i < nv[k]; ++i) sum += __shfl(noise, i, L);
+                            noise = noise * (1.0f / (sum + 1e-8f));
+                        }
+                        if (sub < nv[k]) {
+                            HotRec h = empty_rec();
+                            h.prior = prior; h.meta = static_cast<uint32_t>(my_action[k]);
+                            hot[used + sub] = h;
+                            ColdRec cr;
+                            cr.w_draw = 0.f; cr.noise = noise; cr.parent = leaf[k]; cr.reserved = 0;
+                            cold[used + sub] = cr;
+                        }
+                        if (sub == owner) {
+                            const uint32_t lm = (leaf_meta[k] & ~META_NEDGE_MASK) | META_EXPANDED |
+                                                (static_cast<uint32_t>(nv[k]) << META_NEDGE_SHIFT);
+                            hot[leaf[k]].child_off = used;
+                            hot[leaf[k]].meta = lm;
+                        }
+                        used += nv[k];
+                        expanded_here[k] = true;
+                        ++n_exp;
+                    }
+                }
+            }
+
+            // propagate (MCTS.h:381-402): lane j <-> depth j; the node `dist` levels above the leaf
+            // receives the auxiliary value after `dist` per-ply steps and the value decayed dist times
+            const float g = p.value_decay;
+            const float cst = (1.0f - g) * (1.0f / 3.0f);
+            if (mine[k]) {
+                const int dist = len[k] - 1 - sub;
+                float a = wd, b = w1, c = w2, mm = ml;
+                for (int i = 0; i < dist; ++i) {
+                    if (G::AUX_PLUS_ONE) mm += 1.0f;
+                    if (G::AUX_NEGATE) mm = -mm;
+                    if (g < 1.0f) { a = fmaf(a, g, cst); b = fmaf(b, g, cst); c = fmaf(c, g, cst); }
+                }
+#pragma unroll
+                for (int q = 0; q < KMAX; ++q)
+                    if (first[k] == q) {
+                        rec[q].n_visits += 1; rec[q].w_p1 += b; rec[q].w_p2 += c; rec[q].m_sum += mm;
+                        cdraw[q] += a;
+                    }
+                ++n_backup;
+            }
+            for (int j = sub + L; j < len[k]; j += L) {             // deeper than the first LANES levels
+                const int dist = len[k] - 1 - j;
+                float a = wd, b = w1, c = w2, mm = ml;
+                for (int i = 0; i < dist; ++i) {
+                    if (G::AUX_PLUS_ONE) mm += 1.0f;
+                    if (G::AUX_NEGATE) mm = -mm;
+                    if (g < 1.0f) { a = fmaf(a, g, cst); b = fmaf(b, g, cst); c = fmaf(c, g, cst); }
+                }
+                const int slot = lf.path[flat * G::MAX_PATH + j];
+                HotRec h = hot[slot];
+                h.n_visits += 1; h.w_p1 += b; h.w_p2 += c; h.m_sum += mm;
+                hot[slot].n_visits = h.n_visits;
+                hot[slot].w_p1 = h.w_p1; hot[slot].w_p2 = h.w_p2; hot[slot].m_sum = h.m_sum;
+                cold[slot].w_draw += a;
+                ++n_backup;
+            }
+        }
+        // ---- every distinct node goes back once (statistics only: child_off / meta were written above)
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            if (mine[k] && first[k] == k) {
+                HotRec *d = hot + pslot[k];
+                d->n_visits = rec[k].n_visits; d->n_inflight = rec[k].n_inflight;
+                d->w_p1 = rec[k].w_p1; d->w_p2 = rec[k].w_p2; d->m_sum = rec[k].m_sum;
+                cold[pslot[k]].w_draw = cdraw[k];
+            }
+        }
+        if (sub == 0 && used != used0) ar.used[t] = used;
+    }
+    wave_add_counter(counters, CNT_EXPANSIONS, sub == 0 ? n_exp : 0u);
+    wave_add_counter(counters, CNT_DUP, sub == 0 ? n_dup : 0u);
+    wave_add_counter(counters, CNT_BACKUP, n_backup);
+}
+
 // ------------------------------------------------------------------ leaf gather
 
 // BatchedMCTS.h:141-169 / 254-283 (symmetry, grid export, valid mask) and MCTS_cpp.py:15-20
@@ -875,6 +1115,18 @@ void launch_select(int game, TreeArena ar, RootState rs, LeafBuf lf, SearchParam
 void launch_backprop(int game, TreeArena ar, LeafBuf lf, SearchParams p, int K, bool vl, bool fused,
                      EvalIn in, unsigned long long *counters, int *err, hipStream_t s)
 {
+    static const bool v1 = getenv("AZ_BACKPROP_V1") != nullptr && getenv("AZ_BACKPROP_V1")[0] == '1';
+    if (K <= 4 && !v1) {
+        AZ_DISPATCH(game, {
+            const int tpw = trees_per_wave(G::LANES);
+            const dim3 grid(grid_for(ar.B, tpw)), block(WAVE);
+            if (vl && fused)        hipLaunchKernelGGL((k_backprop_batched<G, true, true, 4>), grid, block, 0, s, ar, lf, p, K, tpw, in, counters, err);
+            else if (vl && !fused)  hipLaunchKernelGGL((k_backprop_batched<G, true, false, 4>), grid, block, 0, s, ar, lf, p, K, tpw, in, counters, err);
+            else if (!vl && fused)  hipLaunchKernelGGL((k_backprop_batched<G, false, true, 1>), grid, block, 0, s, ar, lf, p, K, tpw, in, counters, err);
+            else                    hipLaunchKernelGGL((k_backprop_batched<G, false, false, 1>), grid, block, 0, s, ar, lf, p, K, tpw, in, counters, err);
+        });
+        return;
+    }
     AZ_DISPATCH(game, {
         const int tpw = trees_per_wave(G::LANES);
         const dim3 grid(grid_for(ar.B, tpw)), block(WAVE);
