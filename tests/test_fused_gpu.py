@@ -297,9 +297,13 @@ def test_mfma_attention_block_matches_torch(env):
     g = torch.Generator(device="cuda"); g.manual_seed(2)
     bf = torch.bfloat16
     rnd = lambda *sh: torch.randn(*sh, device="cuda", generator=g)     # noqa: E731
-    pre = (1 + 0.1 * rnd(64)).to(bf); qn = (1 + 0.1 * rnd(16)).to(bf); kn = (1 + 0.1 * rnd(16)).to(bf)
+    pre = (1 + 0.1 * rnd(64)).to(bf); qn0 = (1 + 0.1 * rnd(16)).to(bf); kn = (1 + 0.1 * rnd(16)).to(bf)
     wqkvg = (rnd(196, 64) / 8).to(bf); wo = (rnd(64, 64) / 8).to(bf)
-    for B in (1, 5, 4096, 9001):                 # 9001: more than one sample per wavefront of the grid, ragged
+    # 9001: more than one sample per wavefront of the grid, ragged.  q-norm weights x6: sharp
+    # softmaxes, still inside the bound under which the kernel skips the running maximum;
+    # x40: outside it (scores up to ~2^300 in the kernel's log2 units), the max-subtracting path
+    for B, qscale in ((1, 1.0), (5, 1.0), (4096, 1.0), (9001, 1.0), (300, 6.0), (300, 40.0)):
+        qn = (qn0.float() * qscale).to(bf)
         x = (rnd(B, 42, 64) * 1.2).to(bf)
         y = torch.full_like(x, float("nan"))
         assert L.az_nn_attn_block(x.data_ptr(), pre.data_ptr(), wqkvg.data_ptr(), qn.data_ptr(), kn.data_ptr(),
@@ -309,15 +313,17 @@ def test_mfma_attention_block_matches_torch(env):
         proj = h @ wqkvg.float().t()
         q, k, v = proj[..., :192].view(B, 42, 3, 4, 16).unbind(2)
         gate = torch.sigmoid(proj[..., 192:])
-        q = TF.rms_norm(q, (16,), qn.float(), 1e-5).transpose(1, 2)
-        k = TF.rms_norm(k, (16,), kn.float(), 1e-5).transpose(1, 2)
-        a = TF.scaled_dot_product_attention(q, k, v.transpose(1, 2))
+        # q, k, v are MFMA operands in the kernel, i.e. bf16 (as under the reference's autocast);
+        # sharp softmaxes magnify that rounding, so the comparison rounds them at the same place
+        q = TF.rms_norm(q, (16,), qn.float(), 1e-5).to(bf).float().transpose(1, 2)
+        k = TF.rms_norm(k, (16,), kn.float(), 1e-5).to(bf).float().transpose(1, 2)
+        a = TF.scaled_dot_product_attention(q, k, v.to(bf).float().transpose(1, 2))
         a = a * gate.transpose(1, 2).unsqueeze(-1)
         ref = a.transpose(1, 2).reshape(B, 42, 64) @ wo.float().t() + xf
         torch.cuda.synchronize()
         err = (y.float() - ref).abs()
         assert torch.isfinite(y.float()).all()
-        assert err.max().item() < 8e-2 and err.mean().item() < 6e-3, (B, err.max().item(), err.mean().item())
+        assert err.max().item() < (8e-2 if qscale == 1.0 else 0.2) and err.mean().item() < 6e-3, (B, qscale, err.max().item(), err.mean().item())
 
 
 def test_fused_heads_kernel_matches_torch_heads(env):
