@@ -131,6 +131,39 @@ print(json.dumps(dict(value=B*plies/dt, seconds=dt, positions=B*plies)))
                       f"+ same CNN fp32 on CPU, {r['seconds']:.1f} s"}
 
 
+def conv_roofline(torch, fast, leaves, launches=20):
+    """The kernel with the largest share of a step (one residual convolution block of the
+    evaluator, nn_conv.hip) against the matrix-core roofline: 2 * 42 * 64 * 576 flops per leaf,
+    timed by events on the stream it is launched on, at the bench's leaf count."""
+    import ctypes as C
+    from src.fast_net import glue
+    L = glue()
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    x = (torch.randn((leaves, 42, 64), device=fast.device) * 0.5).to(torch.bfloat16)
+    y = torch.empty_like(x)
+    w, b, g, beta = (getattr(fast, n) for n in fast.res[0])
+
+    def run():
+        L.az_nn_conv_block(x.data_ptr(), 64, w.data_ptr(), b.data_ptr(), g.data_ptr(), beta.data_ptr(), 1, y.data_ptr(),
+                           leaves, 1e-5, None, s)
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(launches):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / launches * 1e3
+    flops = 2.0 * 42 * 64 * 576 * leaves
+    achieved = flops / (us * 1e-6) / 1e12
+    return {"bound": "mfma", "kernel": "k_conv_block<64,norm,residual> (3 of the 6 evaluator launches, ~45 % of a step)",
+            "achieved": round(achieved, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4),
+            "avg_launch_us": round(us, 1), "flops_per_launch": int(flops),
+            "traffic": 2 * leaves * 42 * 64 * 2, "note": "dense bf16 MFMA peak; the kernel's HBM traffic equals its "
+            "algorithmic bytes (profiles/r01_pmc_fetch_write_by_kernel_final.csv)"}
+
+
 def main():
     args = parse()
     import torch
@@ -257,6 +290,8 @@ def main():
             "tree_kernels_share_of_step": round((sel_ms + bp_ms) / (elapsed * 1e3), 4),
             "roofline": roofline,
         }
+        if args.evaluator == "cnn" and sp.fused.fast is not None and getattr(sp.fused.fast, "mfma_conv", False):
+            out["roofline_evaluator"] = conv_roofline(torch, sp.fused.fast, args.games * args.vl_batch)
         if args.table:
             st = sp.fused.table_stats()                  # whole run, warm-up included
             out["config"]["workload"] += ", transposition table 2^%d entries" % args.table
