@@ -216,7 +216,7 @@ struct OthelloDev {
         if (over(s)) return -1;
         uint64_t v = valid_positions(s);
         if (v == 0) return n == 0 ? PASS : -1;
-        if (n >= __popcll(v)) return -1;
+        if (n >= static_cast<int>(__popcll(v))) return -1;
         for (int i = 0; i < n; ++i) v &= v - 1;
         return __ffsll(static_cast<unsigned long long>(v)) - 1;
     }

@@ -41,11 +41,6 @@ struct alignas(8) V4 { uint32_t w[2]; };
 
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
-__device__ __forceinline__ uint16_t to_bf16(float a)
-{
-    const __hip_bfloat16 x = __float2bfloat16(a);
-    return *reinterpret_cast<const uint16_t *>(&x);
-}
 // one v_cvt_pk_bf16_f32 (round to nearest even, NaN preserving)
 __device__ __forceinline__ uint32_t pack2(float a, float b)
 {

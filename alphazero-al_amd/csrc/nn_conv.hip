@@ -52,29 +52,12 @@ struct alignas(16) V8 { uint32_t w[4]; };
 
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
-__device__ __forceinline__ uint16_t to_bf16(float a)
-{
-    const __hip_bfloat16 x = __float2bfloat16(a);
-    return *reinterpret_cast<const uint16_t *>(&x);
-}
 // one v_cvt_pk_bf16_f32 (round to nearest even, NaN preserving)
 __device__ __forceinline__ uint32_t pack2(float a, float b)
 {
     typedef float pk_f32x2 __attribute__((ext_vector_type(2)));
     typedef __bf16 pk_bf16x2 __attribute__((ext_vector_type(2)));
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(pk_f32x2{a, b}, pk_bf16x2));
-}
-__device__ __forceinline__ void unpack8(const V8 &v, float f[8])
-{
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { f[2 * i] = bf_lo(v.w[i]); f[2 * i + 1] = bf_hi(v.w[i]); }
-}
-__device__ __forceinline__ V8 pack8(const float f[8])
-{
-    V8 v;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v.w[i] = pack2(f[2 * i], f[2 * i + 1]);
-    return v;
 }
 // wave-wide sum on the DPP network (the adds carry the lane movement as an operand modifier):
 // 8 VALU instructions and a readlane, against 6 x (ds_bpermute + address + add) for xor-shuffles
@@ -97,20 +80,6 @@ __device__ __forceinline__ float wave_sum(float v)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // packed-f32 arithmetic (v_pk_mul/add/fma_f32): two elements per VALU instruction
 __device__ __forceinline__ f32x2 unpack2(uint32_t w) { return f32x2{bf_lo(w), bf_hi(w)}; }
-__device__ __forceinline__ f32x2 silu2(f32x2 x)
-{
-    const f32x2 t = x * f32x2{-1.44269504f, -1.44269504f};
-    const f32x2 e = f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + f32x2{1.0f, 1.0f};
-    return x * f32x2{__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
-}
-// x * sigmoid(x) with the hardware exp2 / reciprocal (about 1 ulp each; the result is rounded to
-// bf16 right after).  The IEEE divide costs ~10 instructions per element, and this kernel's
-// elementwise work is issued by only four wavefronts per CU.
-__device__ __forceinline__ float silu(float x)
-{
-    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x));
-}
-
 // 16 bytes per lane from global memory straight into LDS at (wave-uniform) lds_off + lane * 16.
 // Written as inline assembly on purpose: when the compiler knows that a global_load_lds is in
 // flight it puts s_waitcnt vmcnt(0) in front of every later LDS read that might alias it, i.e.
@@ -404,6 +373,8 @@ __global__ void __launch_bounds__(256, 2) k_conv_block(const uint16_t *x, const 
             const int q = step / 9;
             const f32x2 x = {acc[q >> 1][2 * (q & 1)], acc[q >> 1][2 * (q & 1) + 1]};
             switch (step % 9) {
+            // SiLU = x / (1 + 2^(-x log2 e)) on the hardware exp2 / reciprocal (about 1 ulp each; the
+            // result is rounded to bf16 right after)
             case 0: e.t = x * f32x2{-1.44269504f, -1.44269504f}; break;
             case 1: e.t.x = __builtin_amdgcn_exp2f(e.t.x); break;
             case 2: e.t.y = __builtin_amdgcn_exp2f(e.t.y); break;
