@@ -275,7 +275,8 @@ def main():
             "metric": "self-play positions/sec (Connect4 n_playout=200, batch=8192 games/GPU, vl_batch=4)",
             "value": round(g_pos / t, 2), "unit": "positions/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(t / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32 tree statistics (u64 bitboards); bf16 autocast network",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "dtype_detail": "tree statistics f32 (positions u64 bitboards, counts i32); network bf16 with f32 accumulation, as the reference's autocast",
             "data": "synthetic: self-play from empty boards, random-init network" if args.evaluator == "cnn"
                     else "synthetic: self-play from empty boards, integer-hash evaluator",
             "config": {"workload": "Connect4 self-play, n_playout=%d, %d games/GPU, vl_batch=%d, evaluator=%s"
