@@ -758,10 +758,9 @@ int az_mcts_dev_select(az_mcts *m, int K, int vl, float *features, uint8_t *vali
         m->last_select_vl = vl != 0;
         const az::SearchParams p = m->params();
         const bool timed = m->profiling && m->ev_select.begin(s);
-        az::launch_select(m->game, m->arena(), m->roots(), ls.view(), p, K, vl != 0, m->counters.p, s);
+        az::launch_select(m->game, m->arena(), m->roots(), ls.view(), p, K, vl != 0, m->counters.p, s, m->call_ctr.p);
         if (timed) m->ev_select.end(s);
         az::launch_export(m->game, ls.view(), p, static_cast<int>(total), true, nullptr, valid_mask, features, s);
-        az::launch_bump_call(m->call_ctr.p, s);
         ++m->select_launches;
     });
 }
@@ -781,7 +780,6 @@ int az_mcts_dev_backprop(az_mcts *m, int K, int vl, const float *probs, const fl
         az::launch_backprop(m->game, m->arena(), ls.view(), m->params(), K, vl != 0, true, in, m->counters.p,
                             m->err.p, s);
         if (timed) m->ev_backprop.end(s);
-        az::launch_bump_call(m->call_ctr.p, s);
         ++m->backprop_launches;
     });
 }

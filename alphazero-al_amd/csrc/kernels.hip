@@ -151,10 +151,14 @@ __global__ void __launch_bounds__(256) k_set_roots(const uint64_t *bb0, const ui
 // with compute_fpu (140-156) and select_edge (163-234) evaluated across the group's lanes.
 template <class G, bool VL>
 __global__ void __launch_bounds__(WAVE) k_select(TreeArena ar, RootState rs, LeafBuf lf, SearchParams p, int K,
-                                                 int tpw, unsigned long long *counters)
+                                                 int tpw, unsigned long long *counters, uint64_t *bump)
 {
     constexpr int L = G::LANES;
     const int lane = threadIdx.x;
+    // Device generator: one new call number per iteration.  Selection draws nothing, and every
+    // kernel that does (gather: symmetry ids; backup: root noise - distinct streams of one call
+    // number) runs after it on the stream, so the bump rides here instead of in launches of its own.
+    if (bump != nullptr && blockIdx.x == 0 && lane == 0) *bump += 1;
     const int sub = lane % L;
     const int grp = lane / L;
     const int tree = blockIdx.x * tpw + grp;
@@ -1102,13 +1106,13 @@ void launch_bump_call(uint64_t *call_ctr, hipStream_t s)
 }
 
 void launch_select(int game, TreeArena ar, RootState rs, LeafBuf lf, SearchParams p, int K, bool vl,
-                   unsigned long long *counters, hipStream_t s)
+                   unsigned long long *counters, hipStream_t s, uint64_t *bump_call)
 {
     AZ_DISPATCH(game, {
         const int tpw = trees_per_wave(G::LANES);
         const dim3 grid(grid_for(ar.B, tpw)), block(WAVE);
-        if (vl) hipLaunchKernelGGL((k_select<G, true>), grid, block, 0, s, ar, rs, lf, p, K, tpw, counters);
-        else    hipLaunchKernelGGL((k_select<G, false>), grid, block, 0, s, ar, rs, lf, p, K, tpw, counters);
+        if (vl) hipLaunchKernelGGL((k_select<G, true>), grid, block, 0, s, ar, rs, lf, p, K, tpw, counters, bump_call);
+        else    hipLaunchKernelGGL((k_select<G, false>), grid, block, 0, s, ar, rs, lf, p, K, tpw, counters, bump_call);
     });
 }
 
