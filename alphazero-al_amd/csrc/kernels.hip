@@ -339,6 +339,207 @@ __global__ void __launch_bounds__(WAVE) k_select(TreeArena ar, RootState rs, Lea
     wave_add_counter(counters, CNT_SIMS, (live && sub == 0) ? static_cast<unsigned>(K) : 0u);
 }
 
+// The K virtual-loss descents of a tree, staggered by ONE LEVEL instead of run one after the
+// other.  Descent k+1 depends on descent k only through what k leaves on the nodes it arrives at
+// (in-flight visits, the EXISTS / TERMINAL bits), and k writes those when it ARRIVES at a node -
+// one level ahead of where a descent that runs a level behind will read them.  So in step s
+// descent j works on its level s - j: all block loads of the step are issued together (up to K
+// independent HBM round trips in flight per tree instead of one), then the descents are
+// processed in ascending j with k_select's arithmetic, unchanged.  A level's stores precede the
+// next step's loads of the same records in the program order of the lane that owns them (lane =
+// sibling index), which is the ordering k_select relies on as well.  depth + K - 1 steps
+// instead of K x depth.  Results are bit-identical to k_select (tests).
+template <class G, int KMAX>
+__global__ void __launch_bounds__(WAVE) k_select_staggered(TreeArena ar, RootState rs, LeafBuf lf, SearchParams p, int K,
+                                                           int tpw, unsigned long long *counters, uint64_t *bump)
+{
+    constexpr int L = G::LANES;
+    const int lane = threadIdx.x;
+    if (bump != nullptr && blockIdx.x == 0 && lane == 0) *bump += 1;
+    const int sub = lane % L;
+    const int grp = lane / L;
+    const int tree = blockIdx.x * tpw + grp;
+    const bool live = grp < tpw && tree < ar.B;
+    const int t = live ? tree : 0;
+
+    HotRec *hot = ar.hot + static_cast<size_t>(t) * ar.S;
+    const ColdRec *cold = ar.cold + static_cast<size_t>(t) * ar.S;
+    const int root = ar.root[t];
+    HotRec rootrec = hot[root];
+    int root_infl = rootrec.n_inflight;
+    GameState rstate;
+    rstate.bb0 = rs.bb0[t]; rstate.bb1 = rs.bb1[t]; rstate.turn = rs.turn[t]; rstate.aux = rs.aux[t];
+    const size_t flat0 = static_cast<size_t>(t) * K;
+
+    // per descent: where it stands (uniform across the group)
+    int cur[KMAX], cur_lane[KMAX], depth[KMAX];
+    bool fin[KMAX];
+    HotRec R[KMAX], c[KMAX];
+    float noise[KMAX];
+    GameState st[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+        cur[j] = root; cur_lane[j] = 0; depth[j] = 0;
+        fin[j] = !live || j >= K;
+        st[j] = rstate;
+        noise[j] = 0.0f;
+        c[j] = empty_rec();
+    }
+    unsigned n_levels = 0, n_terminal = 0;
+
+    for (int step = 0;; ++step) {
+        // ---- all loads of the step first
+        bool stop[KMAX], act[KMAX];
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) {
+            act[j] = !fin[j] && step >= j;
+            stop[j] = true;
+            if (act[j]) {
+                if (step == j) {                                     // the descent starts now: the root as it is NOW
+                    R[j] = rootrec; R[j].n_inflight = root_infl;
+                    if (sub == 0) lf.path[(flat0 + j) * G::MAX_PATH] = root;
+                }
+                const uint32_t meta = R[j].meta;
+                const int E = static_cast<int>((meta & META_NEDGE_MASK) >> META_NEDGE_SHIFT);
+                stop[j] = !(meta & META_EXPANDED) || (meta & META_TERMINAL) || E == 0;   // MCTS.h:250-258
+                c[j] = empty_rec();
+                noise[j] = 0.0f;
+                if (!stop[j] && sub < E) {
+                    c[j] = hot[R[j].child_off + sub];
+                    if (cur[j] == root && p.noise_eps > 0.0f) noise[j] = cold[R[j].child_off + sub].noise;
+                }
+            }
+        }
+        // ---- then the descents in order (the arithmetic of k_select)
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) {
+            if (!act[j]) continue;
+            const size_t flat = flat0 + j;
+            int32_t *path = lf.path + flat * G::MAX_PATH;
+            const uint32_t meta = R[j].meta;
+            const int E = static_cast<int>((meta & META_NEDGE_MASK) >> META_NEDGE_SHIFT);
+            int best = -1;
+            HotRec cc = c[j];
+            bool stp = stop[j];
+            if (!stp) {
+                const bool has = sub < E;
+                const bool is_root = cur[j] == root;
+                const float ne = p.noise_eps;
+                const bool exists = has && (cc.meta & META_EXISTS);
+                const bool real = exists && cc.n_visits > 0;
+                const float pq = mean_q(R[j].n_visits, R[j].w_p1, R[j].w_p2, (meta & META_TURN_P1) != 0);
+                const float seen_term = real ? cc.prior : 0.0f;
+                float seen = 0.0f;
+                if (L <= 8) {
+#pragma unroll
+                    for (int i = 0; i < L - 1; ++i) seen += __shfl(seen_term, i, L);
+                } else {
+                    for (int i = 0; i < E; ++i) seen += __shfl(seen_term, i, L);
+                }
+                const float scale = (1.0f + pq) / 2.0f;
+                const float eff = p.fpu_reduction * scale;
+                float fpu = fmaf(-eff, sqrtf(seen), pq);
+                fpu = (-1.0f < fpu) ? fpu : -1.0f;
+                const int pn_i = R[j].n_visits + R[j].n_inflight;
+                const float parent_n = static_cast<float>(pn_i);
+                const float parent_m = mean_m(R[j].n_visits, R[j].m_sum);
+                const float c_puct = (pn_i >= 0 && pn_i < p.tab_n)
+                    ? p.cpuct_tab[pn_i]
+                    : p.c_init + logf((parent_n + p.c_base + 1.0f) / p.c_base);
+                float eff_prior = cc.prior;
+                if (is_root && ne > 0.0f) eff_prior = fmaf(cc.prior, 1.0f - ne, ne * noise[j]);
+                float q, child_q = 0.0f, child_m = 0.0f;
+                int child_total = 0;
+                if (real) {
+                    child_total = cc.n_visits + cc.n_inflight;
+                    child_q = mean_q(cc.n_visits, cc.w_p1, cc.w_p2, (cc.meta & META_TURN_P1) != 0);
+                    child_m = mean_m(cc.n_visits, cc.m_sum);
+                    q = -child_q;
+                } else if (exists && cc.n_inflight > 0) {
+                    q = fpu;
+                    child_total = cc.n_inflight;
+                } else {
+                    q = fpu;
+                }
+                const float u = c_puct * eff_prior * sqrtf(parent_n) / (1.0f + static_cast<float>(child_total));
+                const float m_util = real ? G::aux_utility(child_m, parent_m, child_q, p) : 0.0f;
+                const float score = q + u + m_util;
+                float sc = (has && score == score) ? score : -INFINITY;
+                int si = sub;
+#pragma unroll
+                for (int o = L / 2; o > 0; o >>= 1) {
+                    const float os = __shfl_xor(sc, o, L);
+                    const int oi = __shfl_xor(si, o, L);
+                    if (os > sc || (os == sc && oi < si)) { sc = os; si = oi; }
+                }
+                best = (sc > -INFINITY) ? si : -1;
+                if (best < 0) stp = true;
+            }
+            if (!stp) {
+                ++n_levels;
+                if (depth[j] == 0) root_infl += p.vl_count;         // MCTS.h:470-475
+                const int action = __shfl(static_cast<int>(cc.meta & META_ACTION_MASK), best, L);
+                G::step(st[j], action);
+                const int res = G::result(st[j]);
+                const int child_slot = R[j].child_off + best;
+                if (sub == best) {
+                    uint32_t nm = cc.meta;
+                    if (!(nm & META_EXISTS))
+                        nm = (nm & ~META_TURN_P1) | META_EXISTS | (st[j].turn == 1 ? META_TURN_P1 : 0u);
+                    if (res >= 0)
+                        nm = (nm & ~META_RESULT_MASK) | META_TERMINAL | (static_cast<uint32_t>(res) << META_RESULT_SHIFT);
+                    cc.n_inflight += p.vl_count;                     // MCTS.h:492
+                    hot[child_slot].n_inflight = cc.n_inflight;
+                    if (nm != cc.meta) { cc.meta = nm; hot[child_slot].meta = nm; }
+                }
+                R[j] = group_bcast<L>(cc, best);
+                cur[j] = child_slot;
+                cur_lane[j] = best;
+                ++depth[j];
+                if (sub == 0) path[depth[j]] = cur[j];
+            } else {
+                uint32_t lm = R[j].meta;
+                bool term = (lm & META_TERMINAL) != 0;
+                int code = static_cast<int>((lm & META_RESULT_MASK) >> META_RESULT_SHIFT);
+                if (!term) {
+                    const int res = G::result(st[j]);
+                    if (res >= 0) {
+                        term = true; code = res;
+                        lm = (lm & ~META_RESULT_MASK) | META_TERMINAL | (static_cast<uint32_t>(res) << META_RESULT_SHIFT);
+                        if (sub == cur_lane[j]) hot[cur[j]].meta = lm;
+                        if (depth[j] == 0) rootrec.meta = lm;
+                    }
+                }
+                if (term) ++n_terminal;
+                uint8_t fl = static_cast<uint8_t>((term ? LEAF_TERMINAL : 0) | (code << LEAF_RESULT_SHIFT));
+                if (depth[j] > 0) fl |= LEAF_VL_APPLIED;
+                if (depth[j] == 0 && !(lm & META_EXPANDED)) fl |= LEAF_ROOT_UNEXPANDED;
+                if (lm & META_EXPANDED) fl |= LEAF_EXPANDED;
+                const int nv = term ? 0 : G::num_valid(st[j]);
+                if (sub == 0) lf.slot[flat] = cur[j];
+                if (sub == 1) lf.bb0[flat] = st[j].bb0;
+                if (sub == 2) lf.bb1[flat] = st[j].bb1;
+                if (sub == 3) lf.turn[flat] = st[j].turn;
+                if (sub == 4) lf.flags[flat] = fl;
+                if (sub == 5) lf.path_len[flat] = depth[j] + 1;
+                if (sub == 6) lf.aux[flat] = st[j].aux;
+                if (sub == 7) lf.nvalid[flat] = static_cast<uint8_t>(nv);
+                fin[j] = true;
+            }
+        }
+        bool all_fin = true;
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) all_fin = all_fin && fin[j];
+        if (__all(all_fin)) break;
+    }
+
+    if (live && sub == 0 && root_infl != rootrec.n_inflight) hot[root].n_inflight = root_infl;
+
+    wave_add_counter(counters, CNT_LEVELS, sub == 0 ? n_levels : 0u);
+    wave_add_counter(counters, CNT_TERMINAL, sub == 0 ? n_terminal : 0u);
+    wave_add_counter(counters, CNT_SIMS, (live && sub == 0) ? static_cast<unsigned>(K) : 0u);
+}
+
 // ------------------------------------------------------------------ virtual-loss removal
 
 // MCTS.h:561-581: every node of a recorded path (root included) loses vl_count in-flight
@@ -833,8 +1034,8 @@ template <int L>
 __device__ __forceinline__ unsigned long long group_ballot(bool pred, int lane)
 {
     const unsigned long long bal = __ballot(pred);
-    if (L == 64) return bal;
-    return (bal >> (lane - lane % L)) & ((1ull << L) - 1ull);
+    constexpr unsigned long long mask = L >= 64 ? ~0ull : ((1ull << (L & 63)) - 1ull);
+    return (bal >> (lane - lane % L)) & mask;
 }
 
 // MCTS.h:90-132: re-root at the child reached by `action` if the reference would have
@@ -1108,6 +1309,13 @@ void launch_bump_call(uint64_t *call_ctr, hipStream_t s)
 void launch_select(int game, TreeArena ar, RootState rs, LeafBuf lf, SearchParams p, int K, bool vl,
                    unsigned long long *counters, hipStream_t s, uint64_t *bump_call)
 {
+    static const bool staggered = getenv("AZ_SELECT_STAGGERED") != nullptr && getenv("AZ_SELECT_STAGGERED")[0] == '1';
+    if (vl && staggered && K >= 2 && K <= 4 && game == Connect4Dev::GAME_ID) {
+        const int tpw = trees_per_wave(Connect4Dev::LANES);
+        hipLaunchKernelGGL((k_select_staggered<Connect4Dev, 4>), dim3(grid_for(ar.B, tpw)), dim3(WAVE), 0, s, ar, rs, lf, p, K,
+                           tpw, counters, bump_call);
+        return;
+    }
     AZ_DISPATCH(game, {
         const int tpw = trees_per_wave(G::LANES);
         const dim3 grid(grid_for(ar.B, tpw)), block(WAVE);
