@@ -286,6 +286,28 @@ def gen_g10():
     save("g10_selfplay_numpy_rng", **out)
 
 
+# ------------------------------------------------------------------ G11: the harness without virtual loss and without td targets
+def gen_g11():
+    """As G10 with the other branches of the harness: vl_batch=1 (the plain search loop,
+    MCTS_cpp.py:110-209), td_steps=0 (7-tuples, game.py:136-141), no temperature switch
+    (temp_decay_moves=0: every move sampled), value_decay < 1 and fpu_reduction 0.4."""
+    from src.game import Game
+    from src.player import AlphaZeroPlayer
+    pv = S.HashPV()
+    np.random.seed(17)
+    player = AlphaZeroPlayer(pv, n_envs=8, c_init=1.25, c_base=500, n_playout=40, alpha=0.0,
+                             is_selfplay=1, noise_epsilon=0.0, fpu_reduction=0.4,
+                             use_symmetry=False, mlh_slope=0.0, mlh_cap=0.2, vl_batch=1, value_decay=0.98)
+    player.mcts.seed(1)
+    data = Game(Env()).batch_self_play(player, 8, temperature=0.8, temp_decay_moves=0, temp_endgame=0, td_steps=0)
+    out = {}
+    for i, (winner, play) in enumerate(data):
+        out[f"g{i}_winner"] = np.array([winner], np.int32)
+        for j, nm in enumerate(("state", "prob", "z", "steps", "aux", "root_wdl", "mask")):
+            out[f"g{i}_{nm}"] = np.array([np.asarray(tup[j]) for tup in play])
+    save("g11_selfplay_plain_search", **out)
+
+
 # ------------------------------------------------------------------ Gomoku Env (surface only: no search binding in the reference)
 def gen_gomoku():
     from src.env_cpp.gomoku import Env as GEnv
@@ -351,8 +373,8 @@ def gen_othello():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rng", "g1", "g2", "search", "g6", "rollout", "g7", "g8", "g10", "gomoku", "othello"]
+    which = sys.argv[1:] or ["rng", "g1", "g2", "search", "g6", "rollout", "g7", "g8", "g10", "g11", "gomoku", "othello"]
     fns = dict(rng=gen_rng, g1=gen_g1, g2=gen_g2, search=gen_search, g6=gen_g6,
-               rollout=gen_rollout, g7=gen_g7, g8=gen_g8, g10=gen_g10, gomoku=gen_gomoku, othello=gen_othello)
+               rollout=gen_rollout, g7=gen_g7, g8=gen_g8, g10=gen_g10, g11=gen_g11, gomoku=gen_gomoku, othello=gen_othello)
     for w in which:
         fns[w]()

@@ -566,6 +566,36 @@ def test_device_selfplay_trajectories_equal_reference_harness_g10(env):
             assert len(ta) == len(tb) and all(type(x) is type(y) and np.array_equal(x, y) for x, y in zip(ta, tb))
 
 
+def test_device_selfplay_trajectories_plain_search_g11(env):
+    """Fixture G11: the same harness on its other branches - no virtual loss (vl_batch 1), no
+    td-step targets (7-tuples), every move sampled (no temperature switch), value decay 0.98,
+    FPU reduction 0.4, no prior scaling.  Bit-exact against the reference's output."""
+    g = load("g11_selfplay_plain_search")
+    net = env["H"].HashEvaluator("cuda")
+    np.random.seed(17)
+    sp = env["SP"].DeviceSelfPlay(net, 8, n_playout=40, vl_batch=1, c_init=1.25, c_base=500, alpha=0.0,
+                                  noise_epsilon=0.0, fpu_reduction=0.4, use_symmetry=False, mlh_slope=0.0,
+                                  mlh_cap=0.2, value_decay=0.98, temperature=0.8, temp_decay_moves=0,
+                                  temp_endgame=0, seed=1, record=True, td_steps=0, refill=False, sampler="reference")
+    for _ in range(43):
+        sp.step()
+        if bool(sp.dead.all()):
+            break
+    games = sorted(sp.drain(), key=lambda t: t[2])
+    assert [t[2] for t in games] == list(range(8))
+    for i, (winner, play, _slot) in enumerate(games):
+        assert winner == int(g[f"g{i}_winner"][0]), i
+        assert all(len(t) == 7 for t in play)
+        for j, nm in enumerate(("state", "prob", "z", "steps", "aux", "root_wdl", "mask")):
+            got = np.array([np.asarray(t[j]) for t in play])
+            ref = g[f"g{i}_{nm}"]
+            assert got.shape == ref.shape and got.dtype == ref.dtype, (i, nm)
+            if ref.dtype.kind == "f":
+                assert np.array_equal(bits(got), bits(ref)), (i, nm)
+            else:
+                assert np.array_equal(got, ref), (i, nm)
+
+
 def test_device_selfplay_recording_with_refill(env):
     """Recording in the production mode (device sampling, finished slots refilled at once):
     structural invariants of every drained game."""
