@@ -455,6 +455,20 @@ def test_device_transposition_table_leaves_the_search_unchanged(env):
     assert w._fused is not None and w._fused.table_log2 == 12 and w._fused.table_stats()["hits"] > 0
     assert np.array_equal(w.get_visits_count(), c0)
     w.refresh_cache(net)
+    # the plain (no virtual loss) loop goes through the table as well
+    plain = []
+    for table in (False, True):
+        w = env["W"].BatchedMCTS(256, 1.4, 400, 0.0, 24, noise_epsilon=0.0, fpu_reduction=0.2, use_symmetry=False,
+                                 mlh_slope=0.1)
+        fs = w._fused_runner(net, True)
+        if table:
+            fs.enable_table(14, verify=True)
+        w.batch_playout(net, boards, turns, vl_batch=1, fused=True)
+        plain.append((w.get_visits_count().copy(), np.array(w.mcts.get_all_root_stats()).copy()))
+        if table:
+            st = fs.table_stats()
+            assert st["mismatches"] == 0 and st["hits"] > 0
+    assert np.array_equal(plain[0][0], plain[1][0]) and np.array_equal(bits(plain[0][1]), bits(plain[1][1]))
 
 
 def test_device_generator_noise_and_symmetry(env):
