@@ -915,8 +915,31 @@ int az_c4_dev_step(uint64_t *bb_p1, uint64_t *bb_p2, int32_t *turns, const int32
     return guarded([&] {
         require(n >= 0, "az_c4_dev_step: negative size");
         if (n == 0) return;
-        az::launch_game_step(AZ_GAME_CONNECT4, bb_p1, bb_p2, turns, actions, done, winner, n, reset_finished != 0,
+        az::launch_game_step(AZ_GAME_CONNECT4, bb_p1, bb_p2, turns, nullptr, actions, done, winner, n, reset_finished != 0,
                              static_cast<hipStream_t>(stream));
+    });
+}
+
+int az_game_dev_step(int game, uint64_t *bb_p1, uint64_t *bb_p2, int32_t *turns, int32_t *aux, const int32_t *actions,
+                     uint8_t *done, int32_t *winner, int64_t n, int reset_finished, void *stream)
+{
+    return guarded([&] {
+        require(game == AZ_GAME_CONNECT4 || game == AZ_GAME_OTHELLO, "az_game_dev_step: unknown game");
+        require(n >= 0, "az_game_dev_step: negative size");
+        if (n == 0) return;
+        az::launch_game_step(game, bb_p1, bb_p2, turns, aux, actions, done, winner, n, reset_finished != 0,
+                             static_cast<hipStream_t>(stream));
+    });
+}
+
+int az_game_dev_valid_mask(int game, const uint64_t *bb_p1, const uint64_t *bb_p2, const int32_t *turns,
+                           const int32_t *aux, uint8_t *mask, int64_t n, void *stream)
+{
+    return guarded([&] {
+        require(game == AZ_GAME_CONNECT4 || game == AZ_GAME_OTHELLO, "az_game_dev_valid_mask: unknown game");
+        require(n >= 0, "az_game_dev_valid_mask: negative size");
+        if (n == 0) return;
+        az::launch_game_valid_mask(game, bb_p1, bb_p2, turns, aux, mask, n, static_cast<hipStream_t>(stream));
     });
 }
 

@@ -46,6 +46,7 @@ struct Connect4Dev {
         const int pieces = __popcll(bb0 | bb1);
         return pieces == 0 ? -1 : ((pieces & 1) ? 0 : 1);
     }
+    __device__ static void start(GameState &s) { s.bb0 = 0; s.bb1 = 0; s.turn = 1; s.aux = -1; }
     __device__ static void import_cells(const int8_t *b, GameState &s)   // Connect4.h:87-129
     {
         uint64_t bb0 = 0, bb1 = 0;
@@ -174,6 +175,10 @@ struct OthelloDev {
         return (sq & own) ? cand : 0ull;
     }
     __device__ static int root_aux(uint64_t, uint64_t) { return 0; }   // import forgets passes (Othello.h:108-110)
+    __device__ static void start(GameState &s)            // Othello.h:62-75
+    {
+        s.bb0 = (1ull << 28) | (1ull << 35); s.bb1 = (1ull << 27) | (1ull << 36); s.turn = 1; s.aux = 0;
+    }
     __device__ static void import_cells(const int8_t *b, GameState &s)  // Othello.h:87-111
     {
         uint64_t bb0 = 0, bb1 = 0;

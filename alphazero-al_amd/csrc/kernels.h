@@ -120,8 +120,10 @@ void launch_root_stats(int game, TreeArena ar, float *stats, hipStream_t s);
 void launch_init_trees(TreeArena ar, hipStream_t s);
 void launch_rollout(int game, LeafBuf lf, SearchParams p, int B, float *policy, float *d, float *p1w, float *p2w,
                     float *ml, uint8_t *is_term, hipStream_t s);
-void launch_game_step(int game, uint64_t *bb0, uint64_t *bb1, int32_t *turns, const int32_t *actions,
+void launch_game_step(int game, uint64_t *bb0, uint64_t *bb1, int32_t *turns, int32_t *aux, const int32_t *actions,
                       uint8_t *done, int32_t *winner, int64_t n, bool reset_finished, hipStream_t s);
+void launch_game_valid_mask(int game, const uint64_t *bb0, const uint64_t *bb1, const int32_t *turns, const int32_t *aux,
+                            uint8_t *mask, int64_t n, hipStream_t s);
 
 void launch_tt_lookup(LeafBuf lf, int n_leaves, TtTable t, const uint64_t *clock, float *probs, float *wdl, float *ml,
                       int32_t *miss_idx, int64_t *miss_count, uint64_t *keys, hipStream_t s);

@@ -1238,9 +1238,11 @@ __global__ void __launch_bounds__(256) k_rollout(LeafBuf lf, SearchParams p, int
 
 // ------------------------------------------------------------------ batched game step
 
-// step + result (Connect4.h:159-203 / Othello.h:206-258) on HBM-resident positions
+// step + result (Connect4.h:159-203 / Othello.h:206-258) on HBM-resident positions.  `aux` is the
+// game's small integer carried from ply to ply (Othello: consecutive passes - the GAME remembers
+// them although a tree forgets them at every import); nullptr: derived as an import derives it.
 template <class G>
-__global__ void __launch_bounds__(256) k_game_step(uint64_t *bb0, uint64_t *bb1, int32_t *turns,
+__global__ void __launch_bounds__(256) k_game_step(uint64_t *bb0, uint64_t *bb1, int32_t *turns, int32_t *aux,
                                                    const int32_t *actions, uint8_t *done, int32_t *winner,
                                                    int64_t n, int reset_finished)
 {
@@ -1250,14 +1252,30 @@ __global__ void __launch_bounds__(256) k_game_step(uint64_t *bb0, uint64_t *bb1,
     if (a < 0 || a >= G::ACTIONS) { done[i] = 0; winner[i] = 0; return; }
     GameState s;
     s.bb0 = bb0[i]; s.bb1 = bb1[i]; s.turn = turns[i];
-    s.aux = G::root_aux(s.bb0, s.bb1);
+    s.aux = aux != nullptr ? aux[i] : G::root_aux(s.bb0, s.bb1);
     G::step(s, a);
     const int res = G::result(s);
     const bool fin = res >= 0;
     done[i] = fin ? 1 : 0;
     winner[i] = res == 1 ? 1 : (res == 2 ? -1 : 0);
-    if (fin && reset_finished) { s.bb0 = 0; s.bb1 = 0; s.turn = 1; }
+    if (fin && reset_finished) G::start(s);
     bb0[i] = s.bb0; bb1[i] = s.bb1; turns[i] = s.turn;
+    if (aux != nullptr) aux[i] = s.aux;
+}
+
+// legal actions of HBM-resident positions, one byte per action (env_common.h `valid_mask()`)
+template <class G>
+__global__ void __launch_bounds__(256) k_game_valid_mask(const uint64_t *bb0, const uint64_t *bb1, const int32_t *turns,
+                                                         const int32_t *aux, uint8_t *mask, int64_t n)
+{
+    const int64_t gid = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t i = gid / G::ACTIONS;
+    const int a = static_cast<int>(gid - i * G::ACTIONS);
+    if (i >= n) return;
+    GameState s;
+    s.bb0 = bb0[i]; s.bb1 = bb1[i]; s.turn = turns[i];
+    s.aux = aux != nullptr ? aux[i] : G::root_aux(s.bb0, s.bb1);
+    mask[gid] = G::valid_in_frame(s, 0, a) ? 1 : 0;
 }
 
 __global__ void k_bump_call(uint64_t *ctr) { *ctr += 1; }
@@ -1407,11 +1425,18 @@ void launch_rollout(int game, LeafBuf lf, SearchParams p, int B, float *policy, 
                                          p2w, ml, is_term));
 }
 
-void launch_game_step(int game, uint64_t *bb0, uint64_t *bb1, int32_t *turns, const int32_t *actions,
+void launch_game_step(int game, uint64_t *bb0, uint64_t *bb1, int32_t *turns, int32_t *aux, const int32_t *actions,
                       uint8_t *done, int32_t *winner, int64_t n, bool reset_finished, hipStream_t s)
 {
     AZ_DISPATCH(game, hipLaunchKernelGGL(k_game_step<G>, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s,
-                                         bb0, bb1, turns, actions, done, winner, n, reset_finished ? 1 : 0));
+                                         bb0, bb1, turns, aux, actions, done, winner, n, reset_finished ? 1 : 0));
+}
+
+void launch_game_valid_mask(int game, const uint64_t *bb0, const uint64_t *bb1, const int32_t *turns, const int32_t *aux,
+                            uint8_t *mask, int64_t n, hipStream_t s)
+{
+    AZ_DISPATCH(game, hipLaunchKernelGGL(k_game_valid_mask<G>, dim3(static_cast<unsigned>((n * G::ACTIONS + 255) / 256)),
+                                         dim3(256), 0, s, bb0, bb1, turns, aux, mask, n));
 }
 
 }  // namespace az

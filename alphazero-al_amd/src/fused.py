@@ -52,6 +52,8 @@ def lib():
         L.az_mcts_profile.argtypes = [vp, i32]
         L.az_mcts_profile_read.argtypes = [vp, C.POINTER(C.c_double * 2), C.POINTER(i64 * 2)]
         L.az_c4_dev_step.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, vp]
+        L.az_game_dev_step.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]
+        L.az_game_dev_valid_mask.argtypes = [i32, vp, vp, vp, vp, vp, i64, vp]
         L.az_mcts_dev_tt_create.argtypes = [vp, i32]
         L.az_mcts_dev_tt_clear.argtypes = [vp, vp]
         L.az_mcts_dev_tt_lookup.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]

@@ -39,17 +39,24 @@ class DeviceSelfPlay:
                  noise_epsilon=0.25, fpu_reduction=0.2, use_symmetry=True, mlh_slope=0.1, mlh_cap=0.2,
                  value_decay=1.0, temperature=1.0, temp_decay_moves=20, temp_endgame=0.0, seed=0,
                  reserve_slots=None, record=False, td_steps=0, refill=True, sampler="device",
-                 max_finished_games=None, table_log2=0):
+                 max_finished_games=None, table_log2=0, game="Connect4", score_utility_factor=0.0, score_scale=8.0):
         self.B = int(n_games)
         self.n_playout = int(n_playout)
         self.vl_batch = int(vl_batch)
         self.temperature, self.temp_decay_moves, self.temp_endgame = temperature, temp_decay_moves, temp_endgame
         if c_base is None:
             c_base = 5 * n_playout                  # server.py:135 (c_base_factor 5)
+        assert game in ("Connect4", "Othello")
+        self.game = game
+        self.game_id = 0 if game == "Connect4" else 1                # AZ_GAME_*
+        # the longest game in plies: 42 stones; Othello: 60 stones + passes (never two in a row
+        # before the end, so < 120)
+        self.MAX_PLIES = 42 if game == "Connect4" else 126
         self.search = BatchedMCTS(self.B, c_init=c_init, c_base=c_base, alpha=alpha, n_playout=n_playout,
-                                  game_name='Connect4', noise_epsilon=noise_epsilon,
+                                  game_name=game, noise_epsilon=noise_epsilon,
                                   fpu_reduction=fpu_reduction, use_symmetry=use_symmetry,
-                                  mlh_slope=mlh_slope, mlh_cap=mlh_cap, value_decay=value_decay)
+                                  mlh_slope=mlh_slope, mlh_cap=mlh_cap, value_decay=value_decay,
+                                  score_utility_factor=score_utility_factor, score_scale=score_scale)
         self.search.seed(seed)
         self.fused = F.FusedSearch(self.search, net)
         if table_log2:
@@ -60,9 +67,13 @@ class DeviceSelfPlay:
         self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(int(seed))
         z = dict(device=dev)
-        self.bb_p1 = torch.zeros(self.B, dtype=torch.int64, **z)
-        self.bb_p2 = torch.zeros(self.B, dtype=torch.int64, **z)
+        # initial position (Connect4: empty; Othello.h:62-75: black = player +1 on (3,4) and (4,3))
+        self.start_p1, self.start_p2 = (0, 0) if game == "Connect4" else ((1 << 28) | (1 << 35), (1 << 27) | (1 << 36))
+        self.bb_p1 = torch.full((self.B,), self.start_p1, dtype=torch.int64, **z)
+        self.bb_p2 = torch.full((self.B,), self.start_p2, dtype=torch.int64, **z)
         self.turn = torch.ones(self.B, dtype=torch.int32, **z)
+        # the game's memory beside the stones (Othello: consecutive passes; Connect4: unused)
+        self.aux = torch.zeros(self.B, dtype=torch.int32, **z)
         self.ply = torch.zeros(self.B, dtype=torch.int32, **z)
         self.counts = torch.zeros((self.B, self.search.action_size), dtype=torch.int32, **z)
         self.actions = torch.zeros(self.B, dtype=torch.int32, **z)
@@ -92,8 +103,7 @@ class DeviceSelfPlay:
             self.fin_slot = torch.zeros(self.G + 1, dtype=torch.int32, **z)
             self.n_finished = torch.zeros((), dtype=torch.int64, **z)
             self.n_dropped = torch.zeros((), dtype=torch.int64, **z)
-
-    MAX_PLIES = 42
+            self.mask_u8 = torch.zeros((self.B, A), dtype=torch.uint8, **z)
 
     def _pick_actions(self):
         """Visit counts -> move: proportional to N^(1/T) while T > 0, arg-max otherwise
@@ -150,9 +160,9 @@ class DeviceSelfPlay:
         tot = visits.sum(1, keepdim=True)
         r["prob"][self.ar, idx] = torch.where(tot > 0, visits / tot.clamp_min(1), torch.zeros_like(visits)).to(torch.float32)
         r["wdl"][self.ar, idx] = self.stats[:, 3:6]
-        occ = (self.bb_p1 | self.bb_p2).unsqueeze(1)
-        top = torch.arange(self.search.action_size, device=self.device, dtype=torch.int64) * 7 + 5
-        r["mask"][self.ar, idx] = ((occ >> top) & 1) == 0
+        F.check(F.lib().az_game_dev_valid_mask(self.game_id, self.bb_p1.data_ptr(), self.bb_p2.data_ptr(), self.turn.data_ptr(),
+                                               self.aux.data_ptr(), self.mask_u8.data_ptr(), self.B, F._stream()))
+        r["mask"][self.ar, idx] = self.mask_u8.bool()
 
     def _record_finished(self, fin):
         """End state of the games that just finished, then their rows move to the finished store."""
@@ -193,9 +203,9 @@ class DeviceSelfPlay:
         F.check(L.az_mcts_dev_prune_roots(self.h, self.actions.data_ptr(), s))
         # with recording the end state has to survive the step: finished boards are reset below
         kernel_refill = 1 if (self.refill and not self.record) else 0
-        F.check(L.az_c4_dev_step(self.bb_p1.data_ptr(), self.bb_p2.data_ptr(), self.turn.data_ptr(),
-                                 self.actions.data_ptr(), self.done.data_ptr(), self.winner.data_ptr(),
-                                 self.B, kernel_refill, s))
+        F.check(L.az_game_dev_step(self.game_id, self.bb_p1.data_ptr(), self.bb_p2.data_ptr(), self.turn.data_ptr(),
+                                   self.aux.data_ptr(), self.actions.data_ptr(), self.done.data_ptr(),
+                                   self.winner.data_ptr(), self.B, kernel_refill, s))
         F.check(L.az_mcts_dev_reset_masked(self.h, self.done.data_ptr(), s))
         fin_b = self.done.bool()
         fin = self.done.to(torch.int64)
@@ -204,9 +214,10 @@ class DeviceSelfPlay:
             self._record_finished(fin_b)
         if self.refill:
             if not kernel_refill:
-                self.bb_p1.masked_fill_(fin_b, 0)
-                self.bb_p2.masked_fill_(fin_b, 0)
+                self.bb_p1.masked_fill_(fin_b, self.start_p1)
+                self.bb_p2.masked_fill_(fin_b, self.start_p2)
                 self.turn.masked_fill_(fin_b, 1)
+                self.aux.masked_fill_(fin_b, 0)
             self.ply = torch.where(fin_b, torch.zeros_like(self.ply), self.ply)
         else:
             self.dead |= fin_b
@@ -231,10 +242,16 @@ class DeviceSelfPlay:
         for g in range(n):
             T = int(lens[g])
             winner = int(winners[g])
-            states = planes_from_bitboards(host["bb1"][g, :T + 1], host["bb2"][g, :T + 1], host["turn"][g, :T + 1])
+            states = planes_from_bitboards(host["bb1"][g, :T + 1], host["bb2"][g, :T + 1], host["turn"][g, :T + 1], self.game)
             winner_z = np.full(T, winner, dtype=np.int32)
             steps_to_end = np.arange(T, 0, -1, dtype=np.int32)
-            aux = steps_to_end                                       # game.py:17-23, Connect4: moves left
+            if self.game == "Othello":                               # game.py:17-30: final disc difference, mover's view
+                diff = int(bin(int(host["bb1"][g, T]) & (2 ** 64 - 1)).count("1")) - int(bin(int(host["bb2"][g, T]) & (2 ** 64 - 1)).count("1"))
+                aux = diff * np.asarray(host["turn"][g, :T], dtype=np.int32)
+                terminal_aux = diff * int(host["turn"][g, T])
+            else:
+                aux = steps_to_end                                   # Connect4: moves left
+                terminal_aux = 0
             probs, masks = host["prob"][g], host["mask"][g]
             # object identities as in game.py:121-157 (one root-WDL object per ply, reused by the
             # td-step column; one zero vector per game): pickle writes shared objects once, so
@@ -246,7 +263,7 @@ class DeviceSelfPlay:
             if k > 0:
                 cols.append([root_wdls[t + k] if t + k < T else zero_wdl for t in range(T)])
             play = list(zip(*cols))
-            terminal = [states[T], np.zeros_like(probs[0]), winner, 0, 0, zero_wdl, np.ones_like(masks[0])]
+            terminal = [states[T], np.zeros_like(probs[0]), winner, 0, terminal_aux, zero_wdl, np.ones_like(masks[0])]
             if k > 0:
                 terminal.append(zero_wdl)
             play.append(tuple(terminal))
@@ -269,21 +286,29 @@ def pack_upload(games):
     return pickle.dumps({'__az__': True, 'data': [g[1] for g in games]}, protocol=pickle.HIGHEST_PROTOCOL)
 
 
-def planes_from_bitboards(bb_p1, bb_p2, turn):
-    """(n,) bitboards (bit 7*col + height) and side to move -> the (n, 3, 6, 7) int8 planes of
-    `Env.current_state()` (env_common.h:93-119): stones of the side to move, stones of the
-    opponent, the turn sign everywhere; row 0 is the top of the board."""
+def planes_from_bitboards(bb_p1, bb_p2, turn, game="Connect4"):
+    """(n,) bitboards and side to move -> the (n, 3, rows, cols) int8 planes of `Env.current_state()`
+    (env_common.h:93-119): stones of the side to move, stones of the opponent, the turn sign
+    everywhere.  Connect4: bit 7*col + height, row 0 is the top of the board; Othello: bit 8*row + col."""
     bb_p1 = np.asarray(bb_p1).astype(np.uint64)
     bb_p2 = np.asarray(bb_p2).astype(np.uint64)
     turn = np.asarray(turn).astype(np.int8)
     n = bb_p1.shape[0]
     own = np.where(turn > 0, bb_p1, bb_p2)
     opp = np.where(turn > 0, bb_p2, bb_p1)
-    out = np.zeros((n, 3, 6, 7), dtype=np.int8)
-    for c in range(7):
-        for h in range(6):
-            bit = np.uint64(7 * c + h)
-            out[:, 0, 5 - h, c] = (own >> bit) & np.uint64(1)
-            out[:, 1, 5 - h, c] = (opp >> bit) & np.uint64(1)
+    if game == "Othello":
+        out = np.zeros((n, 3, 8, 8), dtype=np.int8)
+        for r in range(8):
+            for c in range(8):
+                bit = np.uint64(8 * r + c)
+                out[:, 0, r, c] = (own >> bit) & np.uint64(1)
+                out[:, 1, r, c] = (opp >> bit) & np.uint64(1)
+    else:
+        out = np.zeros((n, 3, 6, 7), dtype=np.int8)
+        for c in range(7):
+            for h in range(6):
+                bit = np.uint64(7 * c + h)
+                out[:, 0, 5 - h, c] = (own >> bit) & np.uint64(1)
+                out[:, 1, 5 - h, c] = (opp >> bit) & np.uint64(1)
     out[:, 2] = turn[:, None, None]
     return out

@@ -162,6 +162,18 @@ int az_mcts_dev_reset_masked(az_mcts *m, const uint8_t *mask, void *stream);
  * with player +1 to move.  Games with actions[i] < 0 are left untouched (done = 0). */
 int az_c4_dev_step(uint64_t *bb_p1, uint64_t *bb_p2, int32_t *turns, const int32_t *actions,
                    uint8_t *done, int32_t *winner, int64_t n, int reset_finished, void *stream);
+/* The same for either game (AZ_GAME_*).  `aux` [n] is the game's small integer carried from ply to
+ * ply - Othello: consecutive passes so far (Othello.h:206-235, the Env keeps them although a tree
+ * forgets them at every import, Othello.h:108-110); NULL: derived from the position as an import
+ * derives it (enough for Connect4).  A finished game with reset_finished != 0 restarts from the
+ * game's initial position (Connect4.h reset / Othello.h:62-75). */
+int az_game_dev_step(int game, uint64_t *bb_p1, uint64_t *bb_p2, int32_t *turns, int32_t *aux,
+                     const int32_t *actions, uint8_t *done, int32_t *winner, int64_t n, int reset_finished,
+                     void *stream);
+/* mask[i, a] = 1 iff action a is legal in position i (what `Env.valid_mask()` returns,
+ * env_common.h; Othello: the pass action only when no placement exists, none after the end). */
+int az_game_dev_valid_mask(int game, const uint64_t *bb_p1, const uint64_t *bb_p2, const int32_t *turns,
+                           const int32_t *aux, uint8_t *mask, int64_t n, void *stream);
 
 /* ---- device transposition table of evaluator outputs (Connect4) -------------------------
  * Replaces, for the device loop, the LRU table of the reference's wrapper (src/Cache.py:5-58 used

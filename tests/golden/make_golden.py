@@ -308,6 +308,29 @@ def gen_g11():
     save("g11_selfplay_plain_search", **out)
 
 
+# ------------------------------------------------------------------ G12: the self-play harness on Othello
+def gen_g12():
+    """Game.batch_self_play + AlphaZeroPlayer on Othello (pass action, terminal disc difference
+    as auxiliary target, score utility in the search): no native randomness, numpy sampling."""
+    from src.game import Game
+    from src.player import AlphaZeroPlayer
+    from src.env_cpp.othello import Env as OEnv
+    pv = S.OthelloHashPV()
+    np.random.seed(23)
+    player = AlphaZeroPlayer(pv, n_envs=8, c_init=1.4, c_base=160, n_playout=32, alpha=0.0,
+                             is_selfplay=1, noise_epsilon=0.25, fpu_reduction=0.2,
+                             use_symmetry=False, game_name='Othello', score_utility_factor=0.15, score_scale=8.0,
+                             vl_batch=4)
+    player.mcts.seed(4)
+    data = Game(OEnv()).batch_self_play(player, 8, temperature=1.0, temp_decay_moves=10, temp_endgame=0, td_steps=2)
+    out = {}
+    for i, (winner, play) in enumerate(data):
+        out[f"g{i}_winner"] = np.array([winner], np.int32)
+        for j, nm in enumerate(("state", "prob", "z", "steps", "aux", "root_wdl", "mask", "fut")):
+            out[f"g{i}_{nm}"] = np.array([np.asarray(tup[j]) for tup in play])
+    save("g12_selfplay_othello", **out)
+
+
 # ------------------------------------------------------------------ Gomoku Env (surface only: no search binding in the reference)
 def gen_gomoku():
     from src.env_cpp.gomoku import Env as GEnv
@@ -373,8 +396,8 @@ def gen_othello():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rng", "g1", "g2", "search", "g6", "rollout", "g7", "g8", "g10", "g11", "gomoku", "othello"]
+    which = sys.argv[1:] or ["rng", "g1", "g2", "search", "g6", "rollout", "g7", "g8", "g10", "g11", "g12", "gomoku", "othello"]
     fns = dict(rng=gen_rng, g1=gen_g1, g2=gen_g2, search=gen_search, g6=gen_g6,
-               rollout=gen_rollout, g7=gen_g7, g8=gen_g8, g10=gen_g10, g11=gen_g11, gomoku=gen_gomoku, othello=gen_othello)
+               rollout=gen_rollout, g7=gen_g7, g8=gen_g8, g10=gen_g10, g11=gen_g11, g12=gen_g12, gomoku=gen_gomoku, othello=gen_othello)
     for w in which:
         fns[w]()

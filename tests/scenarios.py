@@ -448,6 +448,22 @@ def ot_hash_eval(boards, turns):
     return probs, wdl.astype(np.float32), aux
 
 
+class OthelloHashPV:
+    """pv_func for the reference wrapper on Othello (`predict(state, action_mask)` of
+    Othello/Network.py): the (n,3,8,8) relative planes back to board + turn, then ot_hash_eval;
+    the third output is the auxiliary utility itself (already in [-1, 1))."""
+    n_actions = OT_A
+
+    def predict(self, state, action_mask=None):
+        state = np.asarray(state)
+        turns = state[:, 2, 0, 0].astype(np.int32)
+        boards = ((state[:, 0] - state[:, 1]) * turns[:, None, None]).astype(np.int8)
+        probs, wdl, aux = ot_hash_eval(boards, turns)
+        if action_mask is not None:
+            probs = probs * np.asarray(action_mask, dtype=np.float32)
+        return probs, wdl, aux.reshape(-1, 1)
+
+
 class OthelloGame:
     A = OT_A
 

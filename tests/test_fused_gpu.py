@@ -610,6 +610,37 @@ def test_device_selfplay_trajectories_plain_search_g11(env):
                 assert np.array_equal(got, ref), (i, nm)
 
 
+def test_device_selfplay_othello_trajectories_g12(env):
+    """Fixture G12: the reference harness on Othello (pass action, games that end on a full board
+    or on two passes, terminal disc difference as auxiliary target, score utility 0.15 in the
+    search) against the device driver with game="Othello".  Bit-exact."""
+    g = load("g12_selfplay_othello")
+    net = env["H"].OthelloHashEvaluator("cuda")
+    np.random.seed(23)
+    sp = env["SP"].DeviceSelfPlay(net, 8, n_playout=32, vl_batch=4, c_init=1.4, c_base=160, alpha=0.0,
+                                  noise_epsilon=0.25, fpu_reduction=0.2, use_symmetry=False, mlh_slope=0.0,
+                                  temperature=1.0, temp_decay_moves=10, temp_endgame=0, seed=4, record=True,
+                                  td_steps=2, refill=False, sampler="reference", game="Othello",
+                                  score_utility_factor=0.15, score_scale=8.0)
+    for _ in range(130):
+        sp.step()
+        if bool(sp.dead.all()):
+            break
+    assert bool(sp.dead.all())
+    games = sorted(sp.drain(), key=lambda t: t[2])
+    assert [t[2] for t in games] == list(range(8))
+    for i, (winner, play, _slot) in enumerate(games):
+        assert winner == int(g[f"g{i}_winner"][0]), i
+        for j, nm in enumerate(("state", "prob", "z", "steps", "aux", "root_wdl", "mask", "fut")):
+            got = np.array([np.asarray(t[j]) for t in play])
+            ref = g[f"g{i}_{nm}"]
+            assert got.shape == ref.shape and got.dtype == ref.dtype, (i, nm, got.shape, ref.shape, got.dtype, ref.dtype)
+            if ref.dtype.kind == "f":
+                assert np.array_equal(bits(got), bits(ref)), (i, nm)
+            else:
+                assert np.array_equal(got, ref), (i, nm)
+
+
 def test_device_selfplay_recording_with_refill(env):
     """Recording in the production mode (device sampling, finished slots refilled at once):
     structural invariants of every drained game."""
