@@ -1,12 +1,13 @@
-"""Device-side self-play driver: thousands of Connect4 games and their search trees advance
-in lockstep without leaving HBM.
+"""Device-side self-play driver: thousands of games (Connect4 or Othello) and their search trees
+advance in lockstep without leaving HBM.
 
 The reference's driver (src/game.py:65-164 with player.py:333-375) is O(batch) Python per ply
 - it rebuilds the numpy boards from per-game Env objects, samples each action in a Python
 loop and keeps finished games in the batch until the slowest one ends.  Here a ply is
     roots (bitboards in HBM) -> FusedSearch.search (n_playout simulations per tree)
     -> root visit counts (HIP) -> temperature sampling (torch, on device)
-    -> prune_roots with fresh device Dirichlet noise (HIP) -> game step + result (HIP)
+    -> prune_roots with fresh device Dirichlet noise (HIP) -> game step + result (HIP; Othello's
+       pass counter travels with the position, the trees forget it at every ply as the reference's do)
     -> finished games are replaced by fresh ones at once, their trees reset (HIP)
 so every slot plays a live position on every ply.  Same search semantics as
 BatchedMCTS.batch_playout; the schedule of temperatures follows game.py:55-63.
