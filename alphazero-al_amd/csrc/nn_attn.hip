@@ -101,8 +101,10 @@ __global__ void __launch_bounds__(256, 2) k_attn_block(const uint16_t *x, const 
         if (f < 3 * HEADS * 2) {
             const int part = f / (HEADS * 2), h = (f >> 1) % HEADS, sk = f & 1;
             v = *reinterpret_cast<const V8 *>(qkvg + (part * C + h * HD + ll15) * C + 32 * sk + 8 * ll4);
-        } else if (ll15 < HEADS) {
-            v = *reinterpret_cast<const V8 *>(qkvg + (3 * C + ll15) * C + 32 * (f & 1) + 8 * ll4);
+        } else {
+            // the 4 gate rows, repeated four times over the tile's 16 rows: accumulator register r of
+            // EVERY lane group is then head r of the lane's token - no lane has to ask another for it
+            v = *reinterpret_cast<const V8 *>(qkvg + (3 * C + (ll15 & 3)) * C + 32 * (f & 1) + 8 * ll4);
         }
         s_w32[i] = v;
     }
@@ -177,7 +179,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_block(const uint16_t *x, const 
             }
         }
 
-        // ---- gate logits of every token (rows 0..3 of the gate tile = registers of lane group 0)
+        // ---- gate logits of every token (gate tile rows 4q + h = head h: register h of every lane)
         float gate[TT][HEADS];
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -186,8 +188,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_block(const uint16_t *x, const 
             g = MFMA32(frag32(25), hf[tt][1], g);
 #pragma unroll
             for (int h = 0; h < HEADS; ++h) {
-                const float gl = __shfl(g[h], l15, 64);
-                gate[tt][h] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * gl));
+                gate[tt][h] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * g[h]));
             }
         }
 

@@ -284,15 +284,22 @@ __global__ void __launch_bounds__(64 * WPB) k_heads(const uint16_t *tok, az_nn_h
                 wave_lds_sync();
             }
             wave_lds_sync();
-            // ---- weighted column sums: lane = channel
+            // ---- weighted column sums: lane = (channel pair, half of the columns), packed f32
             {
-                const uint16_t *pn = reinterpret_cast<const uint16_t *>(s_pn);
+                const uint32_t *pn2 = reinterpret_cast<const uint32_t *>(s_pn);
+                const int cp = lane & 31, c0 = (lane >> 5) * 4;       // columns c0 .. c0+3 (the 8th does not exist)
 #pragma unroll
-                for (int c = 0; c < COLS; ++c) {
-                    float acc = 0.0f;
+                for (int cc = 0; cc < 4; ++cc) {
+                    const int c = c0 + cc;
+                    if (c < COLS) {
+                        f32x2 acc = {0.0f, 0.0f};
 #pragma unroll
-                    for (int r = 0; r < ROWS; ++r) acc += s_score[r * COLS + c] * bf1(pn + (r * COLS + c) * C + lane);
-                    s_vec[(8 * h + c) * VS + lane] = to_bf16(acc);
+                        for (int r = 0; r < ROWS; ++r) {
+                            const float wt = s_score[r * COLS + c];
+                            acc = __builtin_elementwise_fma(f32x2{wt, wt}, unpack2(pn2[(r * COLS + c) * (C / 2) + cp]), acc);
+                        }
+                        *reinterpret_cast<uint32_t *>(&s_vec[(8 * h + c) * VS + 2 * cp]) = pack2(acc.x, acc.y);
+                    }
                 }
             }
             wave_lds_sync();
