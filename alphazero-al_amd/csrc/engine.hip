@@ -784,6 +784,16 @@ int az_mcts_dev_backprop(az_mcts *m, int K, int vl, const float *probs, const fl
     });
 }
 
+int az_mcts_dev_live_leaves(az_mcts *m, int K, int32_t *leaf_idx, int64_t *leaf_count, void *stream)
+{
+    return guarded([&] {
+        LeafStore &ls = m->last_select_vl ? m->vl_leaf : m->plain_leaf;
+        const size_t total = static_cast<size_t>(m->B) * K;
+        require(K >= 1 && ls.slot.n >= total, "dev_live_leaves: no selection of that width");
+        az::launch_live_leaves(ls.view(), static_cast<int>(total), leaf_idx, leaf_count, static_cast<hipStream_t>(stream));
+    });
+}
+
 // ---- device transposition table ------------------------------------------------------------
 int az_mcts_dev_tt_create(az_mcts *m, int log2_entries)
 {

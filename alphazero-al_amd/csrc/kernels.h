@@ -125,6 +125,7 @@ void launch_game_step(int game, uint64_t *bb0, uint64_t *bb1, int32_t *turns, in
 void launch_game_valid_mask(int game, const uint64_t *bb0, const uint64_t *bb1, const int32_t *turns, const int32_t *aux,
                             uint8_t *mask, int64_t n, hipStream_t s);
 
+void launch_live_leaves(LeafBuf lf, int n_leaves, int32_t *idx, int64_t *count, hipStream_t s);
 void launch_tt_lookup(LeafBuf lf, int n_leaves, TtTable t, const uint64_t *clock, float *probs, float *wdl, float *ml,
                       int32_t *miss_idx, int64_t *miss_count, uint64_t *keys, hipStream_t s);
 void launch_tt_insert(int n_leaves, TtTable t, const uint64_t *clock, const int32_t *miss_idx, const int64_t *miss_count,

@@ -138,7 +138,29 @@ __global__ void __launch_bounds__(256) k_tt_insert(TtTable t, const uint64_t *cl
     if (replaced) atomicAdd(&t.stats[3], 1ull);
 }
 
+// The leaves an evaluator has to see: everything but terminal leaves, whose value comes from the
+// game (the reference's wrapper calls `predict` on the non-terminal rows only, MCTS_cpp.py:275-297).
+__global__ void __launch_bounds__(256) k_live_leaves(LeafBuf lf, int n_leaves, int32_t *idx, int64_t *count)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const bool livel = i < n_leaves && !(lf.flags[i] & LEAF_TERMINAL);
+    const unsigned long long m = __ballot(livel);
+    const int lane = threadIdx.x & 63;
+    int64_t base = 0;
+    if (lane == 0 && m)
+        base = static_cast<int64_t>(atomicAdd(reinterpret_cast<unsigned long long *>(count),
+                                              static_cast<unsigned long long>(__popcll(m))));
+    base = __shfl(base, 0, 64);
+    if (livel) idx[base + __popcll(m & ((1ull << lane) - 1))] = static_cast<int32_t>(i);
+}
+
 }  // namespace
+
+void launch_live_leaves(LeafBuf lf, int n_leaves, int32_t *idx, int64_t *count, hipStream_t s)
+{
+    (void)hipMemsetAsync(count, 0, sizeof(int64_t), s);
+    hipLaunchKernelGGL(k_live_leaves, dim3((n_leaves + 255) / 256), dim3(256), 0, s, lf, n_leaves, idx, count);
+}
 
 void launch_tt_lookup(LeafBuf lf, int n_leaves, TtTable t, const uint64_t *clock, float *probs, float *wdl, float *ml,
                       int32_t *miss_idx, int64_t *miss_count, uint64_t *keys, hipStream_t s)

@@ -54,6 +54,7 @@ def lib():
         L.az_c4_dev_step.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, vp]
         L.az_game_dev_step.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]
         L.az_game_dev_valid_mask.argtypes = [i32, vp, vp, vp, vp, vp, i64, vp]
+        L.az_mcts_dev_live_leaves.argtypes = [vp, i32, vp, vp, vp]
         L.az_mcts_dev_tt_create.argtypes = [vp, i32]
         L.az_mcts_dev_tt_clear.argtypes = [vp, vp]
         L.az_mcts_dev_tt_lookup.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
@@ -142,6 +143,7 @@ class FusedSearch:
         self.use_fast = os.environ.get("AZ_FUSED_FASTNET", "1") != "0"
         # device transposition table (enable_table): off unless asked for
         self.table_log2 = 0
+        self.compact_eval = os.environ.get("AZ_FUSED_COMPACT", "1") != "0"
         self.table_verify = False
         self._tt_bufs = {}
         self.tt_mismatch = None
@@ -246,9 +248,24 @@ class FusedSearch:
                 ml = torch.atan(ml / scale) * (2.0 / 3.141592653589793)
         return probs.contiguous(), wdl.contiguous(), ml.reshape(-1).contiguous()
 
+    def _iteration_compact(self, K, vl):
+        """Evaluator on the non-terminal leaves only (the reference's wrapper does the same,
+        MCTS_cpp.py:275-297): late in a game a sizeable share of the leaves is terminal."""
+        L = lib()
+        feats, mask = self._buffers(K)
+        probs, wdl, ml, rows, n_rows = self._table_buffers(K)
+        s = _stream()
+        check(L.az_mcts_dev_select(self.h, K, vl, feats.data_ptr(), mask.data_ptr(), s))
+        check(L.az_mcts_dev_live_leaves(self.h, K, rows.data_ptr(), n_rows.data_ptr(), s))
+        self.fast.predict_device(feats, mask, rows=rows, n_rows=n_rows, out=(probs, wdl, ml))
+        check(L.az_mcts_dev_backprop(self.h, K, vl, probs.data_ptr(), wdl.data_ptr(), ml.data_ptr(), s))
+        return None
+
     def _iteration(self, K, vl):
         if self.table_log2:
             return self._iteration_with_table(K, vl)
+        if self.compact_eval and self.fast is not None and getattr(self.fast, "supports_compact", False):
+            return self._iteration_compact(K, vl)
         L = lib()
         feats, mask = self._buffers(K)
         s = _stream()

@@ -175,6 +175,11 @@ int az_game_dev_step(int game, uint64_t *bb_p1, uint64_t *bb_p2, int32_t *turns,
 int az_game_dev_valid_mask(int game, const uint64_t *bb_p1, const uint64_t *bb_p2, const int32_t *turns,
                            const int32_t *aux, uint8_t *mask, int64_t n, void *stream);
 
+/* The leaves of the last az_mcts_dev_select that an evaluator has to see - all but the terminal
+ * ones, as the reference's wrapper evaluates them (MCTS_cpp.py:275-297): their flat indices go to
+ * leaf_idx[0 .. *leaf_count) (int32 [n*K] and int64 [1] in DEVICE memory; order unspecified). */
+int az_mcts_dev_live_leaves(az_mcts *m, int K, int32_t *leaf_idx, int64_t *leaf_count, void *stream);
+
 /* ---- device transposition table of evaluator outputs (Connect4) -------------------------
  * Replaces, for the device loop, the LRU table of the reference's wrapper (src/Cache.py:5-58 used
  * by src/MCTS_cpp.py:146-189 and 298-339): key = the symmetrised leaf position + side to move,
