@@ -140,18 +140,31 @@ __global__ void __launch_bounds__(256) k_tt_insert(TtTable t, const uint64_t *cl
 
 // The leaves an evaluator has to see: everything but terminal leaves, whose value comes from the
 // game (the reference's wrapper calls `predict` on the non-terminal rows only, MCTS_cpp.py:275-297).
-__global__ void __launch_bounds__(256) k_live_leaves(LeafBuf lf, int n_leaves, int32_t *idx, int64_t *count)
+// One thread per leaf; the workgroup agrees on its share of the list through LDS, so the global
+// counter sees one atomic per workgroup (a single-workgroup scan was tried: 18 us, slower than
+// the contended atomics it was meant to avoid).
+__global__ void __launch_bounds__(1024) k_live_leaves(LeafBuf lf, int n_leaves, int32_t *idx, int64_t *count)
 {
-    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    __shared__ int s_wave[16];
+    __shared__ long long s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + tid;
     const bool livel = i < n_leaves && !(lf.flags[i] & LEAF_TERMINAL);
     const unsigned long long m = __ballot(livel);
-    const int lane = threadIdx.x & 63;
-    int64_t base = 0;
-    if (lane == 0 && m)
-        base = static_cast<int64_t>(atomicAdd(reinterpret_cast<unsigned long long *>(count),
-                                              static_cast<unsigned long long>(__popcll(m))));
-    base = __shfl(base, 0, 64);
-    if (livel) idx[base + __popcll(m & ((1ull << lane) - 1))] = static_cast<int32_t>(i);
+    if (lane == 0) s_wave[wave] = __popcll(m);
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const int c = s_wave[w];
+        if (w < wave) before += c;
+        total += c;
+    }
+    if (tid == 0)
+        s_base = total ? static_cast<long long>(atomicAdd(reinterpret_cast<unsigned long long *>(count),
+                                                          static_cast<unsigned long long>(total))) : 0;
+    __syncthreads();
+    if (livel) idx[s_base + before + __popcll(m & ((1ull << lane) - 1))] = static_cast<int32_t>(i);
 }
 
 }  // namespace
@@ -159,7 +172,7 @@ __global__ void __launch_bounds__(256) k_live_leaves(LeafBuf lf, int n_leaves, i
 void launch_live_leaves(LeafBuf lf, int n_leaves, int32_t *idx, int64_t *count, hipStream_t s)
 {
     (void)hipMemsetAsync(count, 0, sizeof(int64_t), s);
-    hipLaunchKernelGGL(k_live_leaves, dim3((n_leaves + 255) / 256), dim3(256), 0, s, lf, n_leaves, idx, count);
+    hipLaunchKernelGGL(k_live_leaves, dim3((n_leaves + 1023) / 1024), dim3(1024), 0, s, lf, n_leaves, idx, count);
 }
 
 void launch_tt_lookup(LeafBuf lf, int n_leaves, TtTable t, const uint64_t *clock, float *probs, float *wdl, float *ml,

@@ -61,8 +61,12 @@ def host_cores():
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=30, help="timed plies (one ply in every game each)")
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--lead-in", type=int, default=12,
+                    help="untimed plies played before the warm-up so that the timed region sees games of all ages, "
+                         "as continuous self-play does (SURVEY 8d config C1: whole batches of games, not openings only); "
+                         "0 = start the warm-up from empty boards")
     ap.add_argument("--games", type=int, default=8192, help="games (trees) per GPU")
     ap.add_argument("--n-playout", type=int, default=200)
     ap.add_argument("--vl-batch", type=int, default=4)
@@ -208,6 +212,11 @@ def main():
     L = F.lib()
 
     log(f"rank {rank}: engine + evaluator ready ({args.games} games, n_playout={args.n_playout}, K={args.vl_batch})")
+    for i in range(args.lead_in):
+        sp.step()
+    if args.lead_in:
+        torch.cuda.synchronize()
+        log(f"lead-in: {args.lead_in} plies, {sp.read_totals()['games']} games finished and restarted")
     for i in range(args.warmup):
         tw = time.perf_counter()
         sp.step()
@@ -277,12 +286,13 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(t / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "dtype_detail": "tree statistics f32 (positions u64 bitboards, counts i32); network bf16 with f32 accumulation, as the reference's autocast",
-            "data": "synthetic: self-play from empty boards, random-init network" if args.evaluator == "cnn"
-                    else "synthetic: self-play from empty boards, integer-hash evaluator",
+            "data": ("synthetic: continuous self-play (games of all ages after a %d-ply lead-in from empty boards), "
+                     % args.lead_in if args.lead_in else "synthetic: self-play from empty boards, ")
+                    + ("random-init network" if args.evaluator == "cnn" else "integer-hash evaluator"),
             "config": {"workload": "Connect4 self-play, n_playout=%d, %d games/GPU, vl_batch=%d, evaluator=%s"
                                    % (args.n_playout, args.games, args.vl_batch, args.evaluator),
                        "c_init": 1.4, "c_base": 5 * args.n_playout, "fpu_reduction": 0.2, "dirichlet_alpha": 0.3,
-                       "noise_epsilon": 0.25, "mlh_slope": 0.1, "use_symmetry": True,
+                       "noise_epsilon": 0.25, "mlh_slope": 0.1, "use_symmetry": True, "lead_in_plies": args.lead_in,
                        "parallelism": "independent game shards x%d" % world},
             "sims_per_s": round(g_sims / t, 1), "node_expansions_per_s": round(g_exp / t, 1),
             "node_expansions_per_s_per_gpu": round(g_exp / t / world, 1),
