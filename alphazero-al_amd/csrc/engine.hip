@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "az_mcts.h"
+#include "az_nn.h"
 #include "host_rng.h"
 #include "kernels.h"
 
@@ -174,7 +175,14 @@ struct az_mcts {
     DevBuf<uint64_t> tt_keys;
     uint64_t tt_mask = 0;
     int64_t select_launches = 0, backprop_launches = 0;
+    // leaf batch of az_mcts_dev_search: evaluator inputs, outputs, compact row list, activations
+    DevBuf<float> ev_feat, ev_probs, ev_wdl, ev_ml;
+    DevBuf<uint8_t> ev_mask, ev_scratch;
+    DevBuf<int32_t> ev_rows;
+    DevBuf<int64_t> ev_nrows;
     bool profiling = false;
+    int profile_stride = 1;      // time every profile_stride-th launch of a kind
+    int64_t profile_seen[2] = {0, 0};
     EventRing ev_select, ev_backprop;
 
     // IO buffers of the host entry points
@@ -757,7 +765,7 @@ int az_mcts_dev_select(az_mcts *m, int K, int vl, float *features, uint8_t *vali
         if (vl) m->vl_stride = K;
         m->last_select_vl = vl != 0;
         const az::SearchParams p = m->params();
-        const bool timed = m->profiling && m->ev_select.begin(s);
+        const bool timed = m->profiling && (m->profile_seen[0]++ % m->profile_stride) == 0 && m->ev_select.begin(s);
         az::launch_select(m->game, m->arena(), m->roots(), ls.view(), p, K, vl != 0, m->counters.p, s, m->call_ctr.p);
         if (timed) m->ev_select.end(s);
         az::launch_export(m->game, ls.view(), p, static_cast<int>(total), true, nullptr, valid_mask, features, s);
@@ -776,7 +784,7 @@ int az_mcts_dev_backprop(az_mcts *m, int K, int vl, const float *probs, const fl
         in.policy = probs; in.wdl_rel = wdl_rel; in.moves_left = moves_left;
         in.root_noise = nullptr; in.sym = nullptr;
         hipStream_t s = static_cast<hipStream_t>(stream);
-        const bool timed = m->profiling && m->ev_backprop.begin(s);
+        const bool timed = m->profiling && (m->profile_seen[1]++ % m->profile_stride) == 0 && m->ev_backprop.begin(s);
         az::launch_backprop(m->game, m->arena(), ls.view(), m->params(), K, vl != 0, true, in, m->counters.p,
                             m->err.p, s);
         if (timed) m->ev_backprop.end(s);
@@ -791,6 +799,66 @@ int az_mcts_dev_live_leaves(az_mcts *m, int K, int32_t *leaf_idx, int64_t *leaf_
         const size_t total = static_cast<size_t>(m->B) * K;
         require(K >= 1 && ls.slot.n >= total, "dev_live_leaves: no selection of that width");
         az::launch_live_leaves(ls.view(), static_cast<int>(total), leaf_idx, leaf_count, static_cast<hipStream_t>(stream));
+    });
+}
+
+// The reference's iteration schedule (MCTS_cpp.py:110-113, 217-264: one plain simulation that
+// expands every root, then ceil((n_playout-1)/K) virtual-loss batches) with the evaluator in the
+// loop, issued from native code: per iteration selection + gather, the list of leaves to evaluate,
+// the six evaluator launches, backup.  Nothing here waits for the device once the buffers exist.
+int az_mcts_dev_search(az_mcts *m, const az_nn_model *model, int n_playout, int K, int use_table, void *stream)
+{
+    return guarded([&] {
+        require(model != nullptr, "dev_search: no evaluator model");
+        require(m->game == AZ_GAME_CONNECT4, "dev_search: the native evaluator is the Connect4 network");
+        require(K >= 1 && n_playout >= 0, "dev_search: K must be >= 1 and n_playout >= 0");
+        require(!use_table || m->tt_entries.p != nullptr, "dev_search: no table (az_mcts_dev_tt_create)");
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        HIP_OK(hipSetDevice(m->device));
+        const size_t total = static_cast<size_t>(m->B) * K;
+        const size_t scratch = az_nn_model_scratch_bytes(model, static_cast<int64_t>(total));
+        const int64_t extra = static_cast<int64_t>(n_playout) * m->geo.actions;
+        const bool grows = total > m->vl_leaf.slot.n || total > m->ev_rows.n || scratch > m->ev_scratch.n ||
+                           m->used_bound + extra > m->S || (use_table && m->tt_keys.n < 2 * total);
+        // anything below that allocates, frees or reads a buffer the stream's kernels use waits for them first
+        if (grows) HIP_OK(hipStreamSynchronize(s));
+        if (az_mcts_dev_prepare(m, K, n_playout) != AZ_OK) throw AzError(AZ_ERR_DEVICE, g_last_error);
+        if (total > m->ev_rows.n) {
+            m->ev_feat.ensure(total * 3 * m->geo.cells); m->ev_mask.ensure(total * m->geo.actions);
+            m->ev_probs.ensure(total * m->geo.actions); m->ev_wdl.ensure(total * 3); m->ev_ml.ensure(total);
+            m->ev_rows.ensure(total); m->ev_nrows.ensure(1, true);
+        }
+        m->ev_scratch.ensure(scratch);
+        if (use_table && m->tt_keys.n < 2 * total) { m->tt_keys.ensure(2 * total); ++m->epoch; }
+
+        auto ok = [&](int rc, const char *what) {
+            if (rc != AZ_OK) throw AzError(AZ_ERR_DEVICE, std::string("dev_search: ") + what + ": " + g_last_error);
+        };
+        auto iteration = [&](int k, int vl) {
+            const int64_t n = static_cast<int64_t>(m->B) * k;
+            ok(az_mcts_dev_select(m, k, vl, m->ev_feat.p, m->ev_mask.p, stream), "select");
+            if (use_table)
+                ok(az_mcts_dev_tt_lookup(m, k, m->ev_probs.p, m->ev_wdl.p, m->ev_ml.p, m->ev_rows.p, m->ev_nrows.p, stream), "tt_lookup");
+            else
+                ok(az_mcts_dev_live_leaves(m, k, m->ev_rows.p, m->ev_nrows.p, stream), "live_leaves");
+            if (az_nn_model_forward(model, m->ev_feat.p, m->ev_mask.p, m->ev_probs.p, m->ev_wdl.p, m->ev_ml.p, n,
+                                    m->ev_rows.p, m->ev_nrows.p, m->ev_scratch.p, m->ev_scratch.n, stream) != 0)
+                throw AzError(AZ_ERR_ARG, "dev_search: az_nn_model_forward refused its arguments");
+            if (use_table)
+                ok(az_mcts_dev_tt_insert(m, k, m->ev_rows.p, m->ev_nrows.p, m->ev_probs.p, m->ev_wdl.p, m->ev_ml.p, stream), "tt_insert");
+            ok(az_mcts_dev_backprop(m, k, vl, m->ev_probs.p, m->ev_wdl.p, m->ev_ml.p, stream), "backprop");
+        };
+        int remaining = n_playout;
+        if (K <= 1) {
+            for (; remaining > 0; --remaining) iteration(1, 0);
+            return;
+        }
+        if (remaining > 0) { iteration(1, 0); --remaining; }
+        while (remaining > 0) {
+            const int k = std::min(K, remaining);
+            remaining -= k;
+            iteration(k, 1);
+        }
     });
 }
 
@@ -1001,6 +1069,8 @@ int az_mcts_profile(az_mcts *m, int enable)
             m->ev_backprop.allocate(AZ_PROFILE_MAX);
         }
         m->profiling = enable != 0;
+        m->profile_stride = enable > 1 ? enable : 1;
+        m->profile_seen[0] = m->profile_seen[1] = 0;
     });
 }
 

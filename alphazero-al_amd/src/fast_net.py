@@ -47,6 +47,12 @@ def glue():
             L.az_nn_attn_block.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, f32, vp, vp]
             L.az_nn_heads.argtypes = [vp, C.POINTER(HeadsWeights), vp, vp, vp, vp, i64, f32, vp, vp, vp]
             L.az_nn_stem_embed.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp]
+            L.az_nn_model_create.argtypes = [C.POINTER(ModelWeights), C.POINTER(vp)]
+            L.az_nn_model_destroy.argtypes = [vp]
+            L.az_nn_model_destroy.restype = None
+            L.az_nn_model_scratch_bytes.argtypes = [vp, i64]
+            L.az_nn_model_scratch_bytes.restype = C.c_uint64
+            L.az_nn_model_forward.argtypes = [vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, C.c_uint64, vp]
             _GLUE = L
         except OSError:
             _GLUE = False
@@ -58,6 +64,17 @@ class HeadsWeights(C.Structure):
     _PTRS = ("p_norm", "p_gate_w", "p_fc_w", "p_fc_b", "p_out_w", "d_pool_norm", "d_pool_w", "d_pool_b", "d_norm",
              "d_fc_w", "d_fc_b", "d_out_norm", "d_val_w", "d_val_b", "d_aux_w")
     _fields_ = [(n, C.c_void_p) for n in _PTRS] + [(n, C.c_float) for n in ("p_gate_b", "p_out_b", "d_aux_b", "aux_scale")]
+
+
+MAX_BLOCKS = 8          # AZ_NN_MAX_BLOCKS
+
+
+class ModelWeights(C.Structure):
+    """az_nn_model_weights of include/az_nn.h"""
+    _fields_ = ([(n, C.c_void_p) for n in ("emb_own", "emb_opp", "pos", "stem_w", "stem_b")] + [("n_blocks", C.c_int32)] +
+                [(n, C.c_void_p * MAX_BLOCKS) for n in ("block_w", "block_b", "block_gamma", "block_beta")] +
+                [(n, C.c_void_p) for n in ("pre_w", "qkvg_w", "qn_w", "kn_w", "o_w")] +
+                [("heads", HeadsWeights), ("eps", C.c_float)])
 
 
 class FastConnect4Net(torch.nn.Module):
@@ -141,6 +158,33 @@ class FastConnect4Net(torch.nn.Module):
             hw.d_aux_b = float(self.d_aux_b.reshape(-1)[0].item())
             hw.aux_scale = float(self.aux_target_offset)
             self._heads_w = hw
+
+    def native_model(self):
+        """az_nn_model* over this twin's weight buffers (include/az_nn.h): the whole forward pass as
+        one C call, what az_mcts_dev_search runs inside its loop.  None when the all-HIP path is off."""
+        if not self.supports_compact or not self.fused_stem or len(self.res) > MAX_BLOCKS:
+            return None
+        if getattr(self, "_model", None) is None:
+            w = ModelWeights()
+            for n in ("emb_own", "emb_opp", "pos", "stem_w", "stem_b", "pre_w", "qkvg_w", "qn_w", "kn_w", "o_w"):
+                setattr(w, n, getattr(self, n).data_ptr())
+            w.n_blocks = len(self.res)
+            for i, names in enumerate(self.res):
+                for field, name in zip(("block_w", "block_b", "block_gamma", "block_beta"), names):
+                    getattr(w, field)[i] = getattr(self, name).data_ptr()
+            w.heads = self._heads_w
+            w.eps = 1e-5
+            h = C.c_void_p()
+            if glue().az_nn_model_create(C.byref(w), C.byref(h)) != 0:
+                raise RuntimeError("az_nn_model_create refused the weights")
+            self._model = h
+        return self._model
+
+    def __del__(self):
+        h = getattr(self, "_model", None)
+        if h is not None and _GLUE:
+            _GLUE.az_nn_model_destroy(h)
+            self._model = None
 
     @classmethod
     def from_module(cls, net, dtype=torch.bfloat16, device=None):

@@ -55,6 +55,7 @@ def lib():
         L.az_game_dev_step.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]
         L.az_game_dev_valid_mask.argtypes = [i32, vp, vp, vp, vp, vp, i64, vp]
         L.az_mcts_dev_live_leaves.argtypes = [vp, i32, vp, vp, vp]
+        L.az_mcts_dev_search.argtypes = [vp, vp, i32, i32, i32, vp]
         L.az_mcts_dev_tt_create.argtypes = [vp, i32]
         L.az_mcts_dev_tt_clear.argtypes = [vp, vp]
         L.az_mcts_dev_tt_lookup.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
@@ -162,6 +163,15 @@ class FusedSearch:
             self._eager_runs.clear()
             if self.table_log2:         # cached outputs belong to the old weights (MCTS_cpp.py:361-377)
                 check(lib().az_mcts_dev_tt_clear(self.h, _stream()))
+
+    def _native_model(self):
+        """az_nn_model* when the search can run as one native call: HIP inference twin, compact
+        evaluation on, no verify pass, no graph replay asked for (AZ_FUSED_NATIVE=0 keeps the
+        Python loop over the same entry points)."""
+        if (self.fast is None or self.use_graph or self.table_verify or not self.compact_eval
+                or os.environ.get("AZ_FUSED_NATIVE", "1") == "0" or self.game_name != "Connect4"):
+            return None
+        return self.fast.native_model()
 
     # ------------------------------------------------------------------ transposition table
     def enable_table(self, log2_entries=20, verify=False):
@@ -306,7 +316,7 @@ class FusedSearch:
         gc.collect()
         gc.disable()
         try:
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 outs = self._iteration(K, vl)
         finally:
             if gc_was_on:
@@ -328,6 +338,11 @@ class FusedSearch:
         already in HBM."""
         K = max(1, int(vl_batch))
         self._sync_fast_net()
+        model = self._native_model()
+        if model is not None:
+            # the whole schedule, evaluator included, from native code (az_mcts_dev_search)
+            check(lib().az_mcts_dev_search(self.h, model, int(n_playout), K, 1 if self.table_log2 else 0, _stream()))
+            return
         check(lib().az_mcts_dev_prepare(self.h, K, int(n_playout)))
         if K <= 1:
             for _ in range(n_playout):

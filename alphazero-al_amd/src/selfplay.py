@@ -88,6 +88,14 @@ class DeviceSelfPlay:
         self.sampler, self.refill, self.record, self.td_steps = sampler, bool(refill), bool(record), int(td_steps)
         self.dead = torch.zeros(self.B, dtype=torch.bool, **z)        # refill=False: slots whose game is over
         self.ar = torch.arange(self.B, **z)
+        # constants the step needs, on the device once (a torch.tensor(scalar, device=...) per ply
+        # is a pageable host-to-device copy, which waits for the stream's work)
+        self._c_temp = torch.tensor(float(self.temperature), **z)
+        self._c_temp_end = torch.tensor(float(self.temp_endgame), **z)
+        self._c_B = torch.tensor(self.B, dtype=torch.int64, **z)
+        # the host only enqueues; it may run at most `max_plies_ahead` plies ahead of the device
+        self.max_plies_ahead = 1
+        self._ply_events = []
         if self.record:
             A = self.search.action_size
             self.stats = torch.zeros((self.B, 6 + 8 * A), dtype=torch.float32, **z)
@@ -114,9 +122,7 @@ class DeviceSelfPlay:
         if self.temp_decay_moves <= 0:
             temps = torch.full((self.B,), float(self.temperature), device=self.device)
         else:
-            temps = torch.where(self.ply < self.temp_decay_moves,
-                                torch.tensor(float(self.temperature), device=self.device),
-                                torch.tensor(float(self.temp_endgame), device=self.device))
+            temps = torch.where(self.ply < self.temp_decay_moves, self._c_temp, self._c_temp_end)
         hot = temps > 1e-6
         t_eff = torch.where(hot, temps, torch.ones_like(temps))
         w = visits.clamp_min(0).pow(1.0 / t_eff.unsqueeze(1))
@@ -222,9 +228,15 @@ class DeviceSelfPlay:
             self.ply = torch.where(fin_b, torch.zeros_like(self.ply), self.ply)
         else:
             self.dead |= fin_b
-        self.totals += torch.stack([torch.tensor(self.B, device=self.device), fin.sum(),
+        self.totals += torch.stack([self._c_B, fin.sum(),
                                     (fin * (self.winner == 1)).sum(), (fin * (self.winner == -1)).sum(),
                                     (fin * (self.winner == 0)).sum()])
+        # bounded run-ahead: ~550 launches per ply would otherwise pile up without limit
+        ev = torch.cuda.Event()
+        ev.record()
+        self._ply_events.append(ev)
+        if len(self._ply_events) > self.max_plies_ahead:
+            self._ply_events.pop(0).synchronize()
 
     def drain(self):
         """Finished games since the last call, as the reference's `batch_self_play` returns them:
@@ -277,6 +289,99 @@ class DeviceSelfPlay:
 
     def engine_counters(self):
         return F.counters(self.h)
+
+
+class StreamedSelfPlay:
+    """`n_games` games as `streams` independent DeviceSelfPlay drivers, each with its own engine,
+    HIP stream and host thread.
+
+    One driver's selection and backup kernels keep one wavefront per SIMD busy and end when the
+    deepest tree of the batch is done - most of the chip idles under them; the evaluator kernels
+    are issue bound and fill it.  Games never interact (the reference runs them in separate
+    OpenMP iterations and batches them only for the network, BatchedMCTS.h:88-135), so the batch
+    can be cut into groups whose iterations overlap on the device: one group's tree kernels run
+    under another group's evaluator.  Each game sees exactly the search it would see in a single
+    driver (the evaluator computes every leaf independently of its batch); what changes is which
+    slots share a batch and the device generator's seeds (driver i uses seed * streams + i).
+
+    `step(n)` plays n plies in every game: the drivers' host threads only enqueue work (ctypes and
+    torch release the GIL while they do) and are joined, the device is not waited for - call
+    `synchronize()` for that.  `drain()`, `read_totals()`, `engine_counters()` aggregate over the
+    drivers; slot numbers are global (driver offset + local slot)."""
+
+    def __init__(self, net, n_games, streams=2, seed=0, **kw):
+        from concurrent.futures import ThreadPoolExecutor
+        p = next(net.parameters(), None)
+        self.device = p.device if p is not None else torch.device("cuda", torch.cuda.current_device())
+        # at most three: a process has four hardware queues on ROCm and the NULL stream owns one;
+        # streams that share a queue gain nothing (and, launched thousands of kernels deep from
+        # several host threads, faulted on this software stack)
+        assert 1 <= int(streams) <= 3, "StreamedSelfPlay: 1 to 3 streams"
+        streams = max(1, min(int(streams), int(n_games)))
+        base, extra = divmod(int(n_games), streams)
+        self.sizes = [base + (1 if i < extra else 0) for i in range(streams)]
+        self.offsets = [sum(self.sizes[:i]) for i in range(streams)]
+        self.B = int(n_games)
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(streams)]
+        self.parts = []
+        for i, st in enumerate(self.streams):
+            with torch.cuda.stream(st):
+                self.parts.append(DeviceSelfPlay(net, self.sizes[i], seed=int(seed) * streams + i, **kw))
+        self.synchronize()
+        self._pool = ThreadPoolExecutor(max_workers=streams, thread_name_prefix="az-selfplay")
+
+    def _run(self, i, n):
+        with torch.cuda.device(self.device), torch.cuda.stream(self.streams[i]):
+            for _ in range(n):
+                self.parts[i].step()
+
+    def step(self, n=1):
+        if len(self.parts) == 1:
+            return self._run(0, n)
+        for f in [self._pool.submit(self._run, i, n) for i in range(len(self.parts))]:
+            f.result()
+
+    def synchronize(self):
+        for st in self.streams:
+            st.synchronize()
+
+    def drain(self):
+        self.synchronize()
+        games = []
+        for off, part, st in zip(self.offsets, self.parts, self.streams):
+            with torch.cuda.stream(st):
+                games += [(w, play, slot + off) for (w, play, slot) in part.drain()]
+        return games
+
+    def read_totals(self):
+        self.synchronize()
+        out = {}
+        for part, st in zip(self.parts, self.streams):
+            with torch.cuda.stream(st):
+                for k, v in part.read_totals().items():
+                    out[k] = out.get(k, 0) + v
+        return out
+
+    def engine_counters(self):
+        self.synchronize()
+        out = {}
+        for part in self.parts:
+            for k, v in part.engine_counters().items():
+                out[k] = out.get(k, 0) + v
+        return out
+
+    def table_stats(self):
+        self.synchronize()
+        out = {}
+        for part in self.parts:
+            for k, v in part.fused.table_stats().items():
+                out[k] = out.get(k, 0) + v
+        if out.get("lookups"):
+            out["hit_rate"] = out["hits"] / out["lookups"]
+        return out
+
+    def close(self):
+        self._pool.shutdown(wait=True)
 
 
 def pack_upload(games):

@@ -58,6 +58,9 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("AZ_CPU_CORES", "64"))))
 
 
+PROFILE_EVERY = 4
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,6 +78,10 @@ def parse():
     ap.add_argument("--table", type=int, default=0, metavar="LOG2",
                     help="device transposition table of 2^LOG2 evaluator outputs (the reference's cache_size, "
                          "BASELINE config 4); OFF for the headline number, which evaluates every leaf")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="split the games of a GPU into this many independent drivers, each on its own HIP stream and "
+                         "host thread (selfplay.StreamedSelfPlay): one group's tree kernels run under another group's "
+                         "evaluator kernels; 1 = one driver, one batch of games x vl_batch leaves per iteration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-games", type=int, default=256)
     ap.add_argument("--cpu-plies", type=int, default=2)
@@ -198,7 +205,7 @@ def main():
         dist.barrier()
     from src import fused as F
     from src.az_net import Connect4Net
-    from src.selfplay import DeviceSelfPlay
+    from src.selfplay import StreamedSelfPlay
 
     dev = torch.device("cuda", local)
     torch.manual_seed(1234)                     # same random-init weights on every rank
@@ -207,13 +214,14 @@ def main():
         net = HashEvaluator(dev)
     else:
         net = Connect4Net(device=dev).eval()
-    sp = DeviceSelfPlay(net, args.games, n_playout=args.n_playout, vl_batch=args.vl_batch, seed=rank,
-                        reserve_slots=int(os.environ.get("AZ_RESERVE_SLOTS", "49152")), table_log2=args.table)
+    sp = StreamedSelfPlay(net, args.games, streams=args.streams, n_playout=args.n_playout, vl_batch=args.vl_batch,
+                          seed=rank, reserve_slots=int(os.environ.get("AZ_RESERVE_SLOTS", "49152")),
+                          table_log2=args.table)
+    handles = [part.h for part in sp.parts]
     L = F.lib()
 
     log(f"rank {rank}: engine + evaluator ready ({args.games} games, n_playout={args.n_playout}, K={args.vl_batch})")
-    for i in range(args.lead_in):
-        sp.step()
+    sp.step(args.lead_in)
     if args.lead_in:
         torch.cuda.synchronize()
         log(f"lead-in: {args.lead_in} plies, {sp.read_totals()['games']} games finished and restarted")
@@ -223,16 +231,16 @@ def main():
         torch.cuda.synchronize()
         log(f"warm-up step {i + 1}/{args.warmup}: {time.perf_counter() - tw:.2f} s")
     torch.cuda.synchronize()
-    F.check(L.az_mcts_counters_reset(sp.h))
-    F.check(L.az_mcts_profile(sp.h, 1))
+    for h in handles:
+        F.check(L.az_mcts_counters_reset(h))
+        F.check(L.az_mcts_profile(h, PROFILE_EVERY))      # every 4th selection / backup launch carries an event pair
     t_before = sp.read_totals()
 
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sp.step()
+    sp.step(args.steps)          # the drivers' host threads are joined once, after the last ply is enqueued
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -241,9 +249,13 @@ def main():
     log(f"timed region: {args.steps} steps in {elapsed:.2f} s")
 
     import ctypes as C
-    ms = (C.c_double * 2)(); nl = (C.c_int64 * 2)()
-    F.check(L.az_mcts_profile_read(sp.h, C.byref(ms), C.byref(nl)))
-    F.check(L.az_mcts_profile(sp.h, 0))
+    ms = [0.0, 0.0]; nl = [0, 0]
+    for h in handles:
+        ms_h = (C.c_double * 2)(); nl_h = (C.c_int64 * 2)()
+        F.check(L.az_mcts_profile_read(h, C.byref(ms_h), C.byref(nl_h)))
+        F.check(L.az_mcts_profile(h, 0))
+        for i in range(2):
+            ms[i] += float(ms_h[i]); nl[i] += int(nl_h[i])
     cnt = sp.engine_counters()
     tot = sp.read_totals()
     positions = tot["positions"] - t_before["positions"]
@@ -264,7 +276,7 @@ def main():
         sel_bytes = cnt["levels"] * SEL_BYTES_PER_LEVEL + cnt["sims"] * LEAF_STATE_BYTES
         roofline = None
         if sel_n > 0 and sel_ms > 0:
-            # counters cover every launch of the timed region; events cover the same launches
+            # counters cover every launch of the timed region; events every PROFILE_EVERY-th of them
             launches = max(cnt["select_launches"], 1)
             per_launch_bytes = sel_bytes / launches
             # An event pair brackets more than the kernel: the two records take time on the stream
@@ -290,7 +302,13 @@ def main():
                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                         "kernel": "k_select<VL>", "avg_launch_us": round(avg_ms * 1e3, 2),
                         "avg_event_pair_us": round(raw_ms * 1e3, 2), "empty_event_pair_us": round(pair_ms * 1e3, 2),
-                        "launches_timed": sel_n, "algorithmic_bytes_per_launch": int(per_launch_bytes)}
+                        "launches_timed": sel_n, "algorithmic_bytes_per_launch": int(per_launch_bytes),
+                        "trees_per_launch": args.games // max(args.streams, 1), "concurrent_streams": args.streams}
+            if args.streams > 1:
+                roofline["note"] = ("%d drivers on separate streams: a launch covers %d trees and shares the chip with the "
+                                    "other drivers' evaluator kernels while it runs, so its duration is not the kernel's "
+                                    "isolated time (--streams 1: one launch over all trees, profiles/README.md)"
+                                    % (args.streams, args.games // args.streams))
         out = {
             "metric": "self-play positions/sec (Connect4 n_playout=200, batch=8192 games/GPU, vl_batch=4)",
             "value": round(g_pos / t, 2), "unit": "positions/s", "n_gpus": world, "steps": args.steps,
@@ -304,18 +322,22 @@ def main():
                                    % (args.n_playout, args.games, args.vl_batch, args.evaluator),
                        "c_init": 1.4, "c_base": 5 * args.n_playout, "fpu_reduction": 0.2, "dirichlet_alpha": 0.3,
                        "noise_epsilon": 0.25, "mlh_slope": 0.1, "use_symmetry": True, "lead_in_plies": args.lead_in,
+                       "streams_per_gpu": args.streams,
                        "parallelism": "independent game shards x%d" % world},
             "sims_per_s": round(g_sims / t, 1), "node_expansions_per_s": round(g_exp / t, 1),
             "node_expansions_per_s_per_gpu": round(g_exp / t / world, 1),
             "games_finished": g_games, "mean_select_depth": round(depth, 3), "expansions_per_sim": round(xps, 3),
             "backprop_kernel_avg_us": round(bp_ms / bp_n * 1e3, 2) if bp_n else None,
-            "tree_kernels_share_of_step": round((sel_ms + bp_ms) / (elapsed * 1e3), 4),
+            "tree_kernels_share_of_step": round(((sel_ms / sel_n if sel_n else 0.0) * cnt["select_launches"] +
+                                                 (bp_ms / bp_n if bp_n else 0.0) * cnt["backprop_launches"])
+                                                / (elapsed * 1e3) / max(args.streams, 1), 4),
             "roofline": roofline,
         }
-        if args.evaluator == "cnn" and sp.fused.fast is not None and getattr(sp.fused.fast, "mfma_conv", False):
-            out["roofline_evaluator"] = conv_roofline(torch, sp.fused.fast, args.games * args.vl_batch)
+        fast = sp.parts[0].fused.fast
+        if args.evaluator == "cnn" and fast is not None and getattr(fast, "mfma_conv", False):
+            out["roofline_evaluator"] = conv_roofline(torch, fast, args.games * args.vl_batch // max(args.streams, 1))
         if args.table:
-            st = sp.fused.table_stats()                  # whole run, warm-up included
+            st = sp.table_stats()                        # whole run, warm-up included
             out["config"]["workload"] += ", transposition table 2^%d entries" % args.table
             out["transposition_table"] = {"entries": 1 << args.table, "lookups": st["lookups"], "hits": st["hits"],
                                           "hit_rate": round(st["hit_rate"], 4), "replaced": st["replaced"]}

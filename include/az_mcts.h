@@ -180,6 +180,20 @@ int az_game_dev_valid_mask(int game, const uint64_t *bb_p1, const uint64_t *bb_p
  * leaf_idx[0 .. *leaf_count) (int32 [n*K] and int64 [1] in DEVICE memory; order unspecified). */
 int az_mcts_dev_live_leaves(az_mcts *m, int K, int32_t *leaf_idx, int64_t *leaf_count, void *stream);
 
+/* A whole search as ONE call: the iteration schedule of the reference's wrapper
+ * (MCTS_cpp.py:110-113, 217-264: one plain simulation that expands every root, then virtual-loss
+ * batches of K until n_playout simulations per tree are done) with the evaluator inside the loop -
+ * az_mcts_dev_select, az_mcts_dev_live_leaves (or the table's lookup / insert when use_table != 0),
+ * az_nn_model_forward (include/az_nn.h) on the leaves that need it, az_mcts_dev_backprop - every
+ * launch issued from native code on `stream`, the leaf batch in buffers the engine owns.  Roots
+ * are the ones set by az_mcts_dev_set_roots / import_roots; results are read with
+ * az_mcts_dev_counts / root_stats.  Identical to issuing the same calls one by one (tests).  Engines
+ * on different streams (and host threads) overlap on the device: one engine's selection and
+ * backup kernels, which leave most of the chip idle, run under another engine's evaluator. */
+struct az_nn_model;
+int az_mcts_dev_search(az_mcts *m, const struct az_nn_model *model, int n_playout, int K, int use_table,
+                       void *stream);
+
 /* ---- device transposition table of evaluator outputs (Connect4) -------------------------
  * Replaces, for the device loop, the LRU table of the reference's wrapper (src/Cache.py:5-58 used
  * by src/MCTS_cpp.py:146-189 and 298-339): key = the symmetrised leaf position + side to move,
@@ -225,7 +239,8 @@ int az_mcts_counters_reset(az_mcts *m);
 /* Kernel timing with HIP events recorded on the launch stream around every selection and every
  * expansion/backup kernel issued by the dev_* entry points (bench.py's roofline figures).
  * enable != 0 starts recording (at most AZ_PROFILE_MAX launches per kind are kept between
- * reads); az_mcts_profile_read synchronises and returns, for [0] selection and [1]
+ * reads); enable = n > 1 times every n-th launch of a kind only (an event pair costs the stream
+ * ~5 us, which a bench does not want around every launch); az_mcts_profile_read synchronises and returns, for [0] selection and [1]
  * expansion/backup, the summed kernel time in ms and the number of launches summed. */
 #define AZ_PROFILE_MAX 8192
 int az_mcts_profile(az_mcts *m, int enable);

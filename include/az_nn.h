@@ -98,6 +98,32 @@ int az_nn_heads(const void *tokens, const az_nn_heads_weights *w, const uint8_t 
                 float *moves_left, int64_t batch, float eps, const int32_t *scatter, const int64_t *batch_dev,
                 void *stream);
 
+/* The whole evaluator as one call (nn_model.hip): az_nn_stem_embed, n_blocks x az_nn_conv_block
+ * (64 -> 64, normalised, residual), az_nn_attn_block, az_nn_heads on `stream`, issued from native
+ * code - what alphazero-al_amd/src/fast_net.py does per call from Python.  The object keeps the
+ * POINTERS given here (the caller keeps the arrays alive and unchanged) and is immutable, so it
+ * may be used from several host threads / streams at once; each call brings its own `scratch`
+ * (device memory, az_nn_model_scratch_bytes(batch) bytes: two activation tensors).
+ * rows / n_rows: the compact form described at the top (both NULL = every row 0..batch-1). */
+#define AZ_NN_MAX_BLOCKS 8
+typedef struct az_nn_model_weights {
+    const void *emb_own, *emb_opp, *pos;                    /* as az_nn_stem_embed */
+    const void *stem_w, *stem_b;
+    int32_t n_blocks;                                       /* residual blocks (reference: 3) */
+    const void *block_w[AZ_NN_MAX_BLOCKS], *block_b[AZ_NN_MAX_BLOCKS];          /* as az_nn_conv_block */
+    const void *block_gamma[AZ_NN_MAX_BLOCKS], *block_beta[AZ_NN_MAX_BLOCKS];
+    const void *pre_w, *qkvg_w, *qn_w, *kn_w, *o_w;         /* as az_nn_attn_block */
+    az_nn_heads_weights heads;                              /* as az_nn_heads */
+    float eps;
+} az_nn_model_weights;
+typedef struct az_nn_model az_nn_model;
+int az_nn_model_create(const az_nn_model_weights *w, az_nn_model **out);
+void az_nn_model_destroy(az_nn_model *m);
+uint64_t az_nn_model_scratch_bytes(const az_nn_model *m, int64_t batch);
+int az_nn_model_forward(const az_nn_model *m, const float *features, const uint8_t *mask, float *probs,
+                        float *wdl, float *moves_left, int64_t batch, const int32_t *rows,
+                        const int64_t *n_rows, void *scratch, uint64_t scratch_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -471,6 +471,38 @@ def test_device_transposition_table_leaves_the_search_unchanged(env):
     assert np.array_equal(plain[0][0], plain[1][0]) and np.array_equal(bits(plain[0][1]), bits(plain[1][1]))
 
 
+def test_native_search_call_equals_python_loop(env, monkeypatch):
+    """az_mcts_dev_search (the whole schedule with az_nn_model_forward inside, one C call) against
+    the Python loop over the single entry points: same visit counts and root statistics bit for
+    bit, with virtual-loss batches, with the plain loop, and through the transposition table."""
+    wts = load("g7_checkpoint_weights")
+    net = env["N"].Connect4Net(device="cuda").eval()
+    env["N"].load_reference_weights(net, {k: wts[k] for k in wts.files})
+    rng = np.random.default_rng(21)
+    boards, turns = S.random_openings(rng, 600, 11)      # > 512 trees: below that the loop is a graph replay
+    for K, n_playout, table in ((4, 83, 0), (1, 17, 0), (4, 60, 12), (3, 41, 0)):
+        res = []
+        for native in ("1", "0"):
+            monkeypatch.setenv("AZ_FUSED_NATIVE", native)
+            w = env["W"].BatchedMCTS(600, 1.4, 400, 0.3, n_playout, noise_epsilon=0.25, fpu_reduction=0.2,
+                                     use_symmetry=True, mlh_slope=0.1)
+            w.seed(5)
+            fs = w._fused_runner(net, True)
+            if table:
+                fs.enable_table(table)
+            for rep in range(2):                                      # second search re-uses the trees
+                w.batch_playout(net, boards, turns, vl_batch=K, fused=True)
+            assert (fs._native_model() is not None) == (native == "1")
+            res.append((w.get_visits_count().copy(), np.array(w.mcts.get_all_root_stats()).copy(),
+                        env["F"].counters(fs.h)))
+            if table:
+                assert fs.table_stats()["hits"] > 0
+        (c0, s0, k0), (c1, s1, k1) = res
+        assert c0.sum() > 0 and np.array_equal(c0, c1), (K, n_playout, table)
+        assert np.array_equal(bits(s0), bits(s1))
+        assert k0 == k1
+
+
 def test_device_generator_noise_and_symmetry(env):
     torch = env["torch"]
     rng = np.random.default_rng(9)
@@ -529,6 +561,41 @@ def test_device_selfplay_driver(env):
     used = env["F"].C.c_int64()
     env["F"].check(env["F"].lib().az_mcts_max_used(sp.h, env["F"].C.byref(used)))
     assert 1 < used.value <= env["F"].lib().az_mcts_capacity(sp.h)
+
+
+def test_streamed_selfplay_equals_its_drivers_run_alone(env):
+    """StreamedSelfPlay: the games cut into groups that run on separate HIP streams and host
+    threads.  Every group must play exactly the games it plays when it runs alone with the same
+    seed (concurrency changes the timing, never a result), and the aggregate views must add up."""
+    torch = env["torch"]
+    wts = load("g7_checkpoint_weights")
+    net = env["N"].Connect4Net(device="cuda").eval()
+    env["N"].load_reference_weights(net, {k: wts[k] for k in wts.files})
+    kw = dict(n_playout=24, vl_batch=4, temp_decay_moves=6, record=True, td_steps=2)
+    plies = 14
+    sp = env["SP"].StreamedSelfPlay(net, 1300, streams=2, seed=3, **kw)     # 650 trees per driver: the native loop
+    sp.step(plies)
+    sp.synchronize()
+    tot = sp.read_totals()
+    assert tot["positions"] == plies * 1300 and tot["games"] == tot["p1_wins"] + tot["p2_wins"] + tot["draws"]
+    assert sp.engine_counters()["sims"] == plies * 1300 * 24
+    games = sp.drain()
+    assert len(games) == tot["games"] > 0 and max(g[2] for g in games) >= 650
+    for i, part in enumerate(sp.parts):
+        alone = env["SP"].DeviceSelfPlay(net, sp.sizes[i], seed=3 * 2 + i, **kw)
+        for _ in range(plies):
+            alone.step()
+        torch.cuda.synchronize()
+        assert torch.equal(alone.bb_p1, part.bb_p1) and torch.equal(alone.bb_p2, part.bb_p2)
+        assert torch.equal(alone.ply, part.ply) and torch.equal(alone.totals, part.totals)
+        mine = [g for g in games if sp.offsets[i] <= g[2] < sp.offsets[i] + sp.sizes[i]]
+        ref = alone.drain()
+        assert len(ref) == len(mine)
+        for (w0, play0, slot0), (w1, play1, slot1) in zip(ref, mine):
+            assert w0 == w1 and slot0 + sp.offsets[i] == slot1 and len(play0) == len(play1)
+            for a, b in zip(play0, play1):
+                assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    sp.close()
 
 
 def test_device_selfplay_trajectories_equal_reference_harness_g10(env):
