@@ -754,23 +754,30 @@ int az_mcts_dev_import_roots(az_mcts *m, const int8_t *boards, const int32_t *tu
     });
 }
 
+namespace {
+// zero_count: an int64 in device memory that the selection launch clears on its way (the
+// live-leaf count of az_mcts_dev_search: saves the memset in front of the listing kernel)
+void select_and_gather(az_mcts *m, int K, int vl, float *features, uint8_t *valid_mask, void *stream, int64_t *zero_count)
+{
+    require(K >= 1 && (vl || K == 1), "dev_select: K must be 1 without virtual loss");
+    LeafStore &ls = vl ? m->vl_leaf : m->plain_leaf;
+    const size_t total = static_cast<size_t>(m->B) * K;
+    require(ls.slot.n >= total && m->tab.p, "dev_select: call az_mcts_dev_prepare first");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (vl) m->vl_stride = K;
+    m->last_select_vl = vl != 0;
+    const az::SearchParams p = m->params();
+    const bool timed = m->profiling && (m->profile_seen[0]++ % m->profile_stride) == 0 && m->ev_select.begin(s);
+    az::launch_select(m->game, m->arena(), m->roots(), ls.view(), p, K, vl != 0, m->counters.p, s, m->call_ctr.p, zero_count);
+    if (timed) m->ev_select.end(s);
+    az::launch_export(m->game, ls.view(), p, static_cast<int>(total), true, nullptr, valid_mask, features, s);
+    ++m->select_launches;
+}
+}  // namespace
+
 int az_mcts_dev_select(az_mcts *m, int K, int vl, float *features, uint8_t *valid_mask, void *stream)
 {
-    return guarded([&] {
-        require(K >= 1 && (vl || K == 1), "dev_select: K must be 1 without virtual loss");
-        LeafStore &ls = vl ? m->vl_leaf : m->plain_leaf;
-        const size_t total = static_cast<size_t>(m->B) * K;
-        require(ls.slot.n >= total && m->tab.p, "dev_select: call az_mcts_dev_prepare first");
-        hipStream_t s = static_cast<hipStream_t>(stream);
-        if (vl) m->vl_stride = K;
-        m->last_select_vl = vl != 0;
-        const az::SearchParams p = m->params();
-        const bool timed = m->profiling && (m->profile_seen[0]++ % m->profile_stride) == 0 && m->ev_select.begin(s);
-        az::launch_select(m->game, m->arena(), m->roots(), ls.view(), p, K, vl != 0, m->counters.p, s, m->call_ctr.p);
-        if (timed) m->ev_select.end(s);
-        az::launch_export(m->game, ls.view(), p, static_cast<int>(total), true, nullptr, valid_mask, features, s);
-        ++m->select_launches;
-    });
+    return guarded([&] { select_and_gather(m, K, vl, features, valid_mask, stream, nullptr); });
 }
 
 int az_mcts_dev_backprop(az_mcts *m, int K, int vl, const float *probs, const float *wdl_rel,
@@ -836,11 +843,12 @@ int az_mcts_dev_search(az_mcts *m, const az_nn_model *model, int n_playout, int 
         };
         auto iteration = [&](int k, int vl) {
             const int64_t n = static_cast<int64_t>(m->B) * k;
-            ok(az_mcts_dev_select(m, k, vl, m->ev_feat.p, m->ev_mask.p, stream), "select");
+            select_and_gather(m, k, vl, m->ev_feat.p, m->ev_mask.p, stream, use_table ? nullptr : m->ev_nrows.p);
             if (use_table)
                 ok(az_mcts_dev_tt_lookup(m, k, m->ev_probs.p, m->ev_wdl.p, m->ev_ml.p, m->ev_rows.p, m->ev_nrows.p, stream), "tt_lookup");
             else
-                ok(az_mcts_dev_live_leaves(m, k, m->ev_rows.p, m->ev_nrows.p, stream), "live_leaves");
+                az::launch_live_leaves((vl ? m->vl_leaf : m->plain_leaf).view(), static_cast<int>(n), m->ev_rows.p, m->ev_nrows.p, s,
+                                       false);          // the selection launch cleared the count
             if (az_nn_model_forward(model, m->ev_feat.p, m->ev_mask.p, m->ev_probs.p, m->ev_wdl.p, m->ev_ml.p, n,
                                     m->ev_rows.p, m->ev_nrows.p, m->ev_scratch.p, m->ev_scratch.n, stream) != 0)
                 throw AzError(AZ_ERR_ARG, "dev_search: az_nn_model_forward refused its arguments");

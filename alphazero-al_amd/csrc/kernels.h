@@ -103,7 +103,8 @@ void launch_set_roots(int game, const uint64_t *bb0, const uint64_t *bb1, const 
 void launch_bump_call(uint64_t *call_ctr, hipStream_t s);
 // bump_call: the device generator's call counter, incremented once by the launch (nullptr: not)
 void launch_select(int game, TreeArena ar, RootState rs, LeafBuf lf, SearchParams p, int K, bool vl,
-                   unsigned long long *counters, hipStream_t s, uint64_t *bump_call = nullptr);
+                   unsigned long long *counters, hipStream_t s, uint64_t *bump_call = nullptr,
+                   int64_t *zero = nullptr);   // zero: an int64 the launch clears (the live-leaf count)
 void launch_backprop(int game, TreeArena ar, LeafBuf lf, SearchParams p, int K, bool vl, bool fused,
                      EvalIn in, unsigned long long *counters, int *err, hipStream_t s);
 void launch_remove_vl(int game, TreeArena ar, LeafBuf lf, SearchParams p, int K, int strideK, hipStream_t s);
@@ -125,7 +126,7 @@ void launch_game_step(int game, uint64_t *bb0, uint64_t *bb1, int32_t *turns, in
 void launch_game_valid_mask(int game, const uint64_t *bb0, const uint64_t *bb1, const int32_t *turns, const int32_t *aux,
                             uint8_t *mask, int64_t n, hipStream_t s);
 
-void launch_live_leaves(LeafBuf lf, int n_leaves, int32_t *idx, int64_t *count, hipStream_t s);
+void launch_live_leaves(LeafBuf lf, int n_leaves, int32_t *idx, int64_t *count, hipStream_t s, bool clear_count = true);
 void launch_tt_lookup(LeafBuf lf, int n_leaves, TtTable t, const uint64_t *clock, float *probs, float *wdl, float *ml,
                       int32_t *miss_idx, int64_t *miss_count, uint64_t *keys, hipStream_t s);
 void launch_tt_insert(int n_leaves, TtTable t, const uint64_t *clock, const int32_t *miss_idx, const int64_t *miss_count,

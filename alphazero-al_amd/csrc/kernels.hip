@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(256) k_set_roots(const uint64_t *bb0, const ui
 // with compute_fpu (140-156) and select_edge (163-234) evaluated across the group's lanes.
 template <class G, bool VL>
 __global__ void __launch_bounds__(WAVE) k_select(TreeArena ar, RootState rs, LeafBuf lf, SearchParams p, int K,
-                                                 int tpw, unsigned long long *counters, uint64_t *bump)
+                                                 int tpw, unsigned long long *counters, uint64_t *bump, long long *zero)
 {
     constexpr int L = G::LANES;
     const int lane = threadIdx.x;
@@ -159,6 +159,7 @@ __global__ void __launch_bounds__(WAVE) k_select(TreeArena ar, RootState rs, Lea
     // kernel that does (gather: symmetry ids; backup: root noise - distinct streams of one call
     // number) runs after it on the stream, so the bump rides here instead of in launches of its own.
     if (bump != nullptr && blockIdx.x == 0 && lane == 0) *bump += 1;
+    if (zero != nullptr && blockIdx.x == 0 && lane == 0) *zero = 0;   // the live-leaf count of this iteration
     const int sub = lane % L;
     const int grp = lane / L;
     const int tree = blockIdx.x * tpw + grp;
@@ -351,11 +352,12 @@ __global__ void __launch_bounds__(WAVE) k_select(TreeArena ar, RootState rs, Lea
 // instead of K x depth.  Results are bit-identical to k_select (tests).
 template <class G, int KMAX>
 __global__ void __launch_bounds__(WAVE) k_select_staggered(TreeArena ar, RootState rs, LeafBuf lf, SearchParams p, int K,
-                                                           int tpw, unsigned long long *counters, uint64_t *bump)
+                                                           int tpw, unsigned long long *counters, uint64_t *bump, long long *zero)
 {
     constexpr int L = G::LANES;
     const int lane = threadIdx.x;
     if (bump != nullptr && blockIdx.x == 0 && lane == 0) *bump += 1;
+    if (zero != nullptr && blockIdx.x == 0 && lane == 0) *zero = 0;   // the live-leaf count of this iteration
     const int sub = lane % L;
     const int grp = lane / L;
     const int tree = blockIdx.x * tpw + grp;
@@ -1325,20 +1327,20 @@ void launch_bump_call(uint64_t *call_ctr, hipStream_t s)
 }
 
 void launch_select(int game, TreeArena ar, RootState rs, LeafBuf lf, SearchParams p, int K, bool vl,
-                   unsigned long long *counters, hipStream_t s, uint64_t *bump_call)
+                   unsigned long long *counters, hipStream_t s, uint64_t *bump_call, int64_t *zero)
 {
     static const bool staggered = getenv("AZ_SELECT_STAGGERED") != nullptr && getenv("AZ_SELECT_STAGGERED")[0] == '1';
     if (vl && staggered && K >= 2 && K <= 4 && game == Connect4Dev::GAME_ID) {
         const int tpw = trees_per_wave(Connect4Dev::LANES);
         hipLaunchKernelGGL((k_select_staggered<Connect4Dev, 4>), dim3(grid_for(ar.B, tpw)), dim3(WAVE), 0, s, ar, rs, lf, p, K,
-                           tpw, counters, bump_call);
+                           tpw, counters, bump_call, reinterpret_cast<long long *>(zero));
         return;
     }
     AZ_DISPATCH(game, {
         const int tpw = trees_per_wave(G::LANES);
         const dim3 grid(grid_for(ar.B, tpw)), block(WAVE);
-        if (vl) hipLaunchKernelGGL((k_select<G, true>), grid, block, 0, s, ar, rs, lf, p, K, tpw, counters, bump_call);
-        else    hipLaunchKernelGGL((k_select<G, false>), grid, block, 0, s, ar, rs, lf, p, K, tpw, counters, bump_call);
+        if (vl) hipLaunchKernelGGL((k_select<G, true>), grid, block, 0, s, ar, rs, lf, p, K, tpw, counters, bump_call, reinterpret_cast<long long *>(zero));
+        else    hipLaunchKernelGGL((k_select<G, false>), grid, block, 0, s, ar, rs, lf, p, K, tpw, counters, bump_call, reinterpret_cast<long long *>(zero));
     });
 }
 

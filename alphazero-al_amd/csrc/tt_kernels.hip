@@ -169,9 +169,9 @@ __global__ void __launch_bounds__(1024) k_live_leaves(LeafBuf lf, int n_leaves, 
 
 }  // namespace
 
-void launch_live_leaves(LeafBuf lf, int n_leaves, int32_t *idx, int64_t *count, hipStream_t s)
+void launch_live_leaves(LeafBuf lf, int n_leaves, int32_t *idx, int64_t *count, hipStream_t s, bool clear_count)
 {
-    (void)hipMemsetAsync(count, 0, sizeof(int64_t), s);
+    if (clear_count) (void)hipMemsetAsync(count, 0, sizeof(int64_t), s);
     hipLaunchKernelGGL(k_live_leaves, dim3((n_leaves + 1023) / 1024), dim3(1024), 0, s, lf, n_leaves, idx, count);
 }
 

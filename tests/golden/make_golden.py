@@ -332,6 +332,43 @@ def gen_g12():
 
 
 # ------------------------------------------------------------------ Gomoku Env (surface only: no search binding in the reference)
+def gen_g13():
+    """The reference's Othello network (src/environments/Othello/Network.py) at a small width, with
+    non-trivial BatchNorm statistics and non-zero output layers: weights, inputs, and what forward
+    and predict return on the CPU.  No Othello checkpoint ships with the reference."""
+    import torch
+    from src.environments.Othello.Network import CNN
+    from src.env_cpp.othello import Env as OEnv
+    torch.manual_seed(13)
+    net = CNN(lr=1e-3, h_dim=32, num_res_blocks=2, device="cpu")
+    rng = np.random.default_rng(13)
+    planes, masks = [], []
+    for g in range(24):                                   # positions of random games, every 3rd ply
+        e = OEnv()
+        ply = 0
+        while not e.done():
+            if ply % 3 == g % 3:
+                planes.append(e.current_state()[0].astype(np.float32)); masks.append(np.asarray(e.valid_mask()).astype(bool))
+            e.step(int(rng.choice(e.valid_move())))
+            ply += 1
+    planes, masks = np.stack(planes)[:400], np.stack(masks)[:400]
+    with torch.no_grad():
+        for m in net.modules():                           # zero-initialised outputs would hide the heads
+            if isinstance(m, (torch.nn.Conv2d, torch.nn.Linear)) and float(m.weight.abs().sum()) == 0.0:
+                m.weight.normal_(0.0, 0.1); m.bias.normal_(0.0, 0.1)
+    net.train()
+    with torch.no_grad():
+        for _ in range(3):                                # moves the running statistics off (0, 1)
+            net(torch.from_numpy(planes[:128] * 1.0), action_mask=torch.from_numpy(masks[:128]))
+    net.eval()
+    with torch.no_grad():
+        lp, lv, aux = net(torch.from_numpy(planes), action_mask=torch.from_numpy(masks))
+    p, w, u = net.predict(planes, masks)
+    save("g13_othello_network", planes=planes.astype(np.int8), masks=masks.astype(np.uint8), logp=lp.numpy(), logv=lv.numpy(),
+         aux=aux.numpy(), probs=p, wdl=w, utility=u)
+    save("g13_othello_weights", **{k: v.numpy() for k, v in net.state_dict().items()})
+
+
 def gen_gomoku():
     from src.env_cpp.gomoku import Env as GEnv
     rng = np.random.default_rng(77)
@@ -396,8 +433,8 @@ def gen_othello():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rng", "g1", "g2", "search", "g6", "rollout", "g7", "g8", "g10", "g11", "g12", "gomoku", "othello"]
+    which = sys.argv[1:] or ["rng", "g1", "g2", "search", "g6", "rollout", "g7", "g8", "g10", "g11", "g12", "g13", "gomoku", "othello"]
     fns = dict(rng=gen_rng, g1=gen_g1, g2=gen_g2, search=gen_search, g6=gen_g6,
-               rollout=gen_rollout, g7=gen_g7, g8=gen_g8, g10=gen_g10, g11=gen_g11, g12=gen_g12, gomoku=gen_gomoku, othello=gen_othello)
+               rollout=gen_rollout, g7=gen_g7, g8=gen_g8, g10=gen_g10, g11=gen_g11, g12=gen_g12, g13=gen_g13, gomoku=gen_gomoku, othello=gen_othello)
     for w in which:
         fns[w]()

@@ -335,3 +335,30 @@ def test_gomoku_env_against_reference_fixture(built):
         Env(np.zeros((3, 4), np.float32))
     e.set_params(6, 4)
     assert e.action_size == 36 and e.turn == 1 and e.valid_mask().count(True) == 36
+
+
+def test_othello_network_port_matches_reference_outputs_g13(built):
+    """az_net.OthelloNet against the reference's Othello CNN (fixture G13: a 32-channel instance
+    with trained-looking BatchNorm statistics and non-zero heads, evaluated by the reference on
+    the CPU): its state dict loads strictly, forward and predict agree to float rounding."""
+    import torch
+    from src.az_net import OthelloNet, load_reference_weights
+    g, w = load("g13_othello_network"), load("g13_othello_weights")
+    net = OthelloNet(h_dim=32, num_res_blocks=2)
+    load_reference_weights(net, {k: w[k] for k in w.files})
+    planes = g["planes"].astype(np.float32)
+    masks = g["masks"].astype(bool)
+    with torch.no_grad():
+        lp, lv, aux = net(torch.from_numpy(planes), action_mask=torch.from_numpy(masks))
+    assert np.abs(lp.numpy() - g["logp"]).max() < 2e-5
+    assert np.abs(lv.numpy() - g["logv"]).max() < 2e-5
+    assert np.abs(aux.numpy() - g["aux"]).max() < 2e-5
+    assert g["logp"].std() > 0.05 and np.abs(g["aux"]).max() > 0.01          # the fixture is not a constant
+    p, v, u = net.predict(planes, masks)
+    assert p.shape == (len(planes), 65) and u.shape == (len(planes), 1)
+    assert np.abs(p - g["probs"]).max() < 1e-5 and np.abs(v - g["wdl"]).max() < 1e-5 and np.abs(u - g["utility"]).max() < 1e-5
+    with pytest.raises(ValueError):
+        net(torch.from_numpy(planes[:2]))                                     # the mask is an input feature
+    fresh = OthelloNet(h_dim=32, num_res_blocks=1)                            # zero heads: uniform outputs
+    p, v, u = fresh.predict(planes[:4], masks[:4])
+    assert np.allclose(p, 1 / 65, atol=1e-6) and np.allclose(v, 1 / 3, atol=1e-6) and np.allclose(u, 0, atol=1e-7)

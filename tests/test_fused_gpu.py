@@ -767,3 +767,39 @@ def test_fused_path_othello_bit_exact_vs_oracle(env):
         w.prune_roots(acts)
         for i in range(48):
             t[i] = S.OthelloGame.advance(b[i], int(t[i]), int(acts[i]))
+
+
+def test_fused_othello_with_network(env):
+    """BASELINE config 3's evaluator through the device loop: the Othello network (az_net.OthelloNet,
+    fixture G13 weights) as a torch module under autocast, fused path vs host path - same simulation
+    budget, near-equal root Q, mostly equal best moves - and the self-play driver on top of it."""
+    torch = env["torch"]
+    w13 = load("g13_othello_weights")
+    net = env["N"].OthelloNet(h_dim=32, num_res_blocks=2, device="cuda")
+    env["N"].load_reference_weights(net, {k: w13[k] for k in w13.files})
+    rng = np.random.default_rng(3)
+    boards, turns = S.ot_openings(rng, 96, 20, 0)
+    res = []
+    for fused in (True, False):
+        w = env["W"].BatchedMCTS(96, 1.4, 800, 0.0, 120, noise_epsilon=0.0, fpu_reduction=0.2, use_symmetry=False,
+                                 game_name="Othello", score_utility_factor=0.15, score_scale=8.0)
+        w.batch_playout(net, boards, turns, vl_batch=4, fused=fused)
+        assert (w._fused is not None) == fused
+        res.append((w.get_visits_count(), np.array(w.mcts.get_all_root_stats())))
+    (c1, s1), (c2, s2) = res
+    assert (s1[:, 0] == 120).all() and (s2[:, 0] == 120).all()
+    assert (c1.sum(1) == 119).all() and (c2.sum(1) == 119).all()
+    assert np.abs(s1[:, 1] - s2[:, 1]).mean() < 0.05
+    assert (np.argmax(c1, 1) == np.argmax(c2, 1)).mean() > 0.7
+    sp = env["SP"].DeviceSelfPlay(net, 128, n_playout=32, vl_batch=4, seed=1, game="Othello", temp_decay_moves=8,
+                                  score_utility_factor=0.15, record=True)
+    for _ in range(70):
+        sp.step()
+    tot = sp.read_totals()
+    assert tot["positions"] == 70 * 128 and sp.engine_counters()["sims"] == 70 * 128 * 32
+    games = sp.drain()
+    assert len(games) == tot["games"] > 0
+    for winner, play, slot in games:
+        end = play[-1][0]
+        own, opp = int(end[0].sum()), int(end[1].sum())
+        assert winner == np.sign(own - opp) * int(end[2][0, 0]) and 4 < own + opp <= 64
