@@ -39,7 +39,7 @@ def _run(cmd):
 def build_engine(force=False):
     os.makedirs(LIB, exist_ok=True)
     out = os.path.join(LIB, "libaz_mcts.so")
-    srcs = [os.path.join(CSRC, f) for f in ("kernels.hip", "tt_kernels.hip", "engine.hip", "nn_kernels.hip", "nn_conv.hip", "nn_attn.hip", "nn_heads.hip", "nn_model.hip")]
+    srcs = [os.path.join(CSRC, f) for f in ("kernels.hip", "tt_kernels.hip", "engine.hip", "nn_kernels.hip", "nn_conv.hip", "nn_attn.hip", "nn_heads.hip", "nn_model.hip", "nn_othello.hip")]
     deps = srcs + [os.path.join(CSRC, f) for f in ("kernels.h", "tree_layout.h", "host_rng.h")] + \
         [os.path.join(INC, "az_mcts.h"), os.path.join(INC, "az_nn.h")]
     if force or _stale(out, deps):

@@ -1,0 +1,230 @@
+// nn_othello.hip - the 3x3 convolutions of the reference's Othello network (256 channels on
+// 10x10 / 8x8 maps; Othello/Network.py:22-66, 129-139) as an implicit-GEMM MFMA kernel.
+//
+// ~97 % of that network's ~1 GFLOP per leaf is eight such convolutions.  One layer here is
+//
+//   y = [silu]( post_s * conv3x3( pad( [pre_s * x + pre_b] ) ) + post_b  [+ residual] )
+//
+// on NHWC bf16 activations: the BatchNorm in FRONT of a convolution (residual blocks) is an
+// affine applied while the sample is copied into LDS - the zero padding stays zero, which is why
+// it cannot be folded into the weights - and the BatchNorm BEHIND one is an affine on the fp32
+// accumulators.  Roundings follow the reference under bf16 autocast: the normalised input, the
+// convolution (+ affine) output and the sum with the residual are each rounded to bf16.
+//
+// Mapping (v_mfma_f32_16x16x32_bf16, out^T = W . X^T as in nn_conv.hip):
+//   workgroup = one sample, 4 wavefronts; wavefront w owns output channels 64w .. 64w+63
+//               (4 channel tiles) for ALL token tiles of the sample (7 at 10x10, 4 at 8x8):
+//               112 accumulator VGPRs, 4 MFMAs per LDS read;
+//   B operand  = the sample's zero-padded image in LDS, 16-byte chunks XOR-swizzled with the
+//               cell index so that the 16 tokens of a read hit distinct bank slots;
+//   A operand  = weights, 1.18 MB per layer: too large for registers or LDS, they stream from
+//               L2 in FRAGMENT ORDER (packed once on the host: [k step][channel tile][lane][8]),
+//               so a wavefront's four fragments of a k step are one contiguous 4 KB, fetched
+//               one k step ahead of their use;
+//   epilogue   = accumulators -> affine -> bf16 -> LDS (token major, swizzled) -> a coalesced
+//               pass that adds the residual, applies SiLU and writes whole 16-byte vectors.
+// Two workgroups share a CU (73.7 KB of LDS each), so one's copy / epilogue phases overlap the
+// other's MFMA phase.
+#include <hip/hip_bf16.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "az_nn.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int COUT = 256;
+constexpr int ROWB = COUT * 2;            // bytes of one output token
+
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ uint32_t pack2(float a, float b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+__device__ __forceinline__ float round_bf(float v) { return bf_lo(pack2(v, 0.0f) & 0xffffu); }
+__device__ __forceinline__ float silu(float v) { return __fdividef(v, 1.0f + __expf(-v)); }
+
+template <int CIN, int HI, int PAD, bool PRE, bool RES, bool SILU>
+__global__ void __launch_bounds__(256, 2) k_oth_conv(const uint16_t *x, const uint16_t *wp, const float *pre_s,
+                                                     const float *pre_b, const float *post_s, const float *post_b,
+                                                     const uint16_t *res, uint16_t *y, int64_t B)
+{
+    constexpr int PW = HI + 2 * PAD;          // padded width
+    constexpr int HO = PW - 2;                // output width
+    constexpr int NT = HO * HO;               // output tokens
+    constexpr int T = (NT + 15) / 16;         // token tiles
+    constexpr int CELLB = CIN * 2;            // bytes per image cell
+    constexpr int CPC = CIN / 8;              // 16-byte chunks per cell
+    constexpr int KEYM = CPC < 16 ? CPC - 1 : 15;
+    constexpr int KPT = CIN / 32;             // k steps per tap
+    constexpr int KS = 9 * KPT;
+    static_assert(!RES || PAD == 1, "the residual has the output's geometry");
+    static_assert(256 % CPC == 0, "a thread keeps its channel chunk over the copy loop");
+
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, tl = lane & 15;
+
+    // top-left cell of every token's window in the padded image
+    int cell0[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        int token = t * 16 + tl;
+        token = token < NT ? token : NT - 1;
+        cell0[t] = (token / HO) * PW + (token % HO);
+    }
+    // the pre-affine of the channel chunk this thread copies
+    float ps[8], pb[8];
+    if (PRE) {
+        const int c = tid % CPC;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ps[j] = pre_s[c * 8 + j]; pb[j] = pre_b[c * 8 + j]; }
+    }
+    const uint16_t *wlane = wp + static_cast<size_t>(wave * 4) * 512 + lane * 8;
+
+    for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+        // ---- copy: sample -> zero-padded, swizzled image (the BatchNorm in front of the convolution rides here)
+        const uint16_t *xs = x + b * (HI * HI * CIN);
+        for (int v = tid; v < PW * PW * CPC; v += 256) {
+            const int cell = v / CPC, c = v % CPC;
+            const int iy = cell / PW - PAD, ix = cell % PW - PAD;
+            uint4 val = make_uint4(0u, 0u, 0u, 0u);
+            if (iy >= 0 && iy < HI && ix >= 0 && ix < HI) {
+                val = *reinterpret_cast<const uint4 *>(xs + (iy * HI + ix) * CIN + c * 8);
+                if (PRE) {
+                    uint32_t *wv = reinterpret_cast<uint32_t *>(&val);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        wv[j] = pack2(bf_lo(wv[j]) * ps[2 * j] + pb[2 * j], bf_hi(wv[j]) * ps[2 * j + 1] + pb[2 * j + 1]);
+                }
+            }
+            *reinterpret_cast<uint4 *>(smem + cell * CELLB + ((c ^ (cell & KEYM)) << 4)) = val;
+        }
+        __syncthreads();
+
+        // ---- implicit GEMM: 4 channel tiles x T token tiles per wavefront
+        f32x4 acc[4][T];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 a_cur[4], a_nxt[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_cur[i] = *reinterpret_cast<const bf16x8 *>(wlane + i * 512);
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int tapcell = (tap / 3) * PW + (tap % 3);
+#pragma unroll
+            for (int kc = 0; kc < KPT; ++kc) {
+                const int ks = tap * KPT + kc;
+                const int nx = ks + 1 < KS ? ks + 1 : ks;             // the last step re-reads itself
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    a_nxt[i] = *reinterpret_cast<const bf16x8 *>(wlane + static_cast<size_t>(nx) * (16 * 512) + i * 512);
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const int p = cell0[t] + tapcell;
+                    const bf16x8 bv = *reinterpret_cast<const bf16x8 *>(smem + p * CELLB + ((((kc << 2) | g) ^ (p & KEYM)) << 4));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur[i], bv, acc[i][t], 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a_cur[i] = a_nxt[i];
+            }
+        }
+        __syncthreads();                       // every wavefront is done with the image
+
+        // ---- accumulators -> affine -> bf16 -> token-major stage in LDS (16-byte chunks swizzled by token)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ch = (wave * 4 + i) * 16 + g * 4;
+            const f32x4 s4 = *reinterpret_cast<const f32x4 *>(post_s + ch);
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(post_b + ch);
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int token = t * 16 + tl;
+                if (token < NT) {
+                    const f32x4 v = acc[i][t] * s4 + b4;
+                    uint2 o;
+                    o.x = pack2(v[0], v[1]);
+                    o.y = pack2(v[2], v[3]);
+                    *reinterpret_cast<uint2 *>(smem + token * ROWB + ((((ch >> 3)) ^ (token & 15)) << 4) + ((ch & 7) << 1)) = o;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- coalesced pass: [+ residual] -> [SiLU] -> global
+        uint16_t *ys = y + b * (NT * COUT);
+        const uint16_t *rs = RES ? res + b * (NT * COUT) : nullptr;
+        for (int v = tid; v < NT * 32; v += 256) {
+            const int token = v >> 5, cc = v & 31;
+            uint4 val = *reinterpret_cast<const uint4 *>(smem + token * ROWB + ((cc ^ (token & 15)) << 4));
+            uint32_t *wv = reinterpret_cast<uint32_t *>(&val);
+            uint4 rv = make_uint4(0u, 0u, 0u, 0u);
+            if (RES) rv = *reinterpret_cast<const uint4 *>(rs + token * COUT + cc * 8);
+            const uint32_t *rw = reinterpret_cast<const uint32_t *>(&rv);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float lo = bf_lo(wv[j]), hi = bf_hi(wv[j]);
+                if (RES) { lo = round_bf(lo + bf_lo(rw[j])); hi = round_bf(hi + bf_hi(rw[j])); }
+                if (SILU) { lo = silu(lo); hi = silu(hi); }
+                wv[j] = pack2(lo, hi);
+            }
+            *reinterpret_cast<uint4 *>(ys + token * COUT + cc * 8) = val;
+        }
+        __syncthreads();                       // the stage is the next sample's image
+    }
+}
+
+template <int CIN, int HI, int PAD, bool PRE, bool RES, bool SILU>
+int launch(const void *x, const void *wp, const float *pre_s, const float *pre_b, const float *post_s,
+           const float *post_b, const void *res, void *y, int64_t B, hipStream_t s)
+{
+    constexpr int PW = HI + 2 * PAD, HO = PW - 2;
+    constexpr int IMG = PW * PW * CIN * 2, STAGE = HO * HO * ROWB;
+    constexpr int SMEM = IMG > STAGE ? IMG : STAGE;
+    auto kern = k_oth_conv<CIN, HI, PAD, PRE, RES, SILU>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
+            return 2;
+        attr_set = true;
+    }
+    const unsigned grid = static_cast<unsigned>(B < 512 ? B : 512);      // two workgroups per CU, persistent over samples
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), SMEM, s, static_cast<const uint16_t *>(x),
+                       static_cast<const uint16_t *>(wp), pre_s, pre_b, post_s, post_b,
+                       static_cast<const uint16_t *>(res), static_cast<uint16_t *>(y), B);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int az_nn_othello_conv(const void *x, const void *w_packed, const float *pre_scale, const float *pre_shift,
+                                  const float *post_scale, const float *post_shift, const void *residual, void *y,
+                                  int64_t batch, int c_in, int h_in, int pad, int apply_silu, void *stream)
+{
+    if (batch <= 0 || x == nullptr || w_packed == nullptr || y == nullptr || post_scale == nullptr || post_shift == nullptr)
+        return 1;
+    if ((pre_scale == nullptr) != (pre_shift == nullptr)) return 1;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool pre = pre_scale != nullptr, res = residual != nullptr;
+#define AZ_OTH(CIN, HI, PAD, PRE, RES, SILU) \
+    return launch<CIN, HI, PAD, PRE, RES, SILU>(x, w_packed, pre_scale, pre_shift, post_scale, post_shift, residual, y, batch, s)
+    if (c_in == 32 && h_in == 8 && pad == 2 && !pre && !res && apply_silu) AZ_OTH(32, 8, 2, false, false, true);
+    if (c_in == 256 && h_in == 10 && pad == 1 && pre && !res && apply_silu) AZ_OTH(256, 10, 1, true, false, true);
+    if (c_in == 256 && h_in == 10 && pad == 1 && pre && res && apply_silu) AZ_OTH(256, 10, 1, true, true, true);
+    if (c_in == 256 && h_in == 10 && pad == 1 && !pre && !res && apply_silu) AZ_OTH(256, 10, 1, false, false, true);
+    if (c_in == 256 && h_in == 10 && pad == 0 && !pre && !res && apply_silu) AZ_OTH(256, 10, 0, false, false, true);
+    if (c_in == 256 && h_in == 8 && pad == 1 && !pre && !res && apply_silu) AZ_OTH(256, 8, 1, false, false, true);
+#undef AZ_OTH
+    return 1;
+}

@@ -1,0 +1,131 @@
+"""Inference twin of the Othello network (az_net.OthelloNet / the reference's Othello CNN) for the
+device loop: its eight 256-channel 3x3 convolutions - ~97 % of the ~1 GFLOP a leaf costs - run on
+the hand-written MFMA kernel of csrc/nn_othello.hip (include/az_nn.h: az_nn_othello_conv), with
+the BatchNorms as affines inside it; the embedding and the thin ends of the two heads (a 1x1
+convolution, an 8-channel bottleneck, three small linears) stay torch operations.
+
+Activations are NHWC bf16 between layers; weights are packed once into the kernel's fragment
+order.  `predict_device(x, mask)` returns what the reference's `predict` returns
+(Othello/Network.py:229-261) without leaving the device: probabilities over the 65 actions,
+relative WDL, and the score utility atan(disc difference / score_scale) * 2/pi.
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.nn.functional as F
+
+from src.fast_net import glue
+
+
+def _bn_affine(bn):
+    scale = (bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps))
+    shift = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
+    return scale.contiguous(), shift.contiguous()
+
+
+def pack_conv_weight(w):
+    """(256, C_in, 3, 3) -> bf16 in the kernel's A-fragment order [tap][k chunk of 32][channel tile]
+    [lane = 16 * k group + channel][8 consecutive input channels]."""
+    co, ci = w.shape[0], w.shape[1]
+    assert co == 256 and ci % 32 == 0 and tuple(w.shape[2:]) == (3, 3)
+    t = w.detach().to(torch.bfloat16).permute(2, 3, 1, 0).reshape(9, ci // 32, 4, 8, 16, 16)   # tap, kc, g, j, tile, tl
+    return t.permute(0, 1, 4, 2, 5, 3).contiguous()
+
+
+class FastOthelloNet(torch.nn.Module):
+    aux_target_offset = 64
+    n_actions = 65
+
+    @staticmethod
+    def recognises(net):
+        need = ("piece_emb", "pos_emb", "legal_emb", "stem", "policy_head", "dual_head", "orbit_map")
+        if not all(hasattr(net, n) for n in need):
+            return False
+        w = net.stem[0].weight
+        return tuple(w.shape) == (256, 32, 3, 3) and glue() is not None and hasattr(glue(), "az_nn_othello_conv")
+
+    def __init__(self, net):
+        super().__init__()
+        self.net = net
+        self.device = net.stem[0].weight.device
+        self.score_scale = float(getattr(net, "score_scale", 8.0))
+        L = glue()
+        vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
+        L.az_nn_othello_conv.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
+        self._L = L
+        dev = self.device
+        ones = torch.ones(256, device=dev)
+        zeros = torch.zeros(256, device=dev)
+        mods = list(net.stem)
+        n_blocks = sum(1 for m in mods if hasattr(m, "conv1"))
+        self.layers = []        # (packed weight, pre, post, residual?, c_in, h_in, pad)
+        self._keep = []
+
+        def add(conv, pre, post, res, c_in, h_in, pad):
+            wp = pack_conv_weight(conv.weight)
+            pre = tuple(t.to(dev) for t in pre) if pre is not None else None
+            post = tuple(t.to(dev) for t in post) if post is not None else (ones, zeros)
+            self.layers.append((wp, pre, post, res, c_in, h_in, pad))
+
+        add(mods[0], None, _bn_affine(mods[1]), False, 32, 8, 2)
+        for blk in mods[3:3 + n_blocks]:
+            add(blk.conv1, _bn_affine(blk.norm1), None, False, 256, 10, 1)
+            add(blk.conv2, _bn_affine(blk.norm2), None, True, 256, 10, 1)
+        add(mods[3 + n_blocks], None, _bn_affine(mods[4 + n_blocks]), False, 256, 10, 1)
+        self.n_body = len(self.layers)
+        ps = net.policy_head.stem
+        add(ps[0], None, _bn_affine(ps[1]), False, 256, 10, 0)
+        add(ps[4], None, _bn_affine(ps[5]), False, 256, 8, 1)
+        ph = net.policy_head
+        self.board_w = ph.board_out.weight.detach().float().reshape(256).contiguous()
+        self.board_b = float(ph.board_out.bias.detach().float().item())
+
+    def _conv(self, x, layer, residual, stream):
+        wp, pre, post, res, c_in, h_in, pad = layer
+        bsz = x.shape[0]
+        ho = h_in + 2 * pad - 2
+        y = torch.empty((bsz, ho, ho, 256), dtype=torch.bfloat16, device=self.device)
+        rc = self._L.az_nn_othello_conv(x.data_ptr(), wp.data_ptr(), None if pre is None else pre[0].data_ptr(),
+                                        None if pre is None else pre[1].data_ptr(), post[0].data_ptr(), post[1].data_ptr(),
+                                        residual.data_ptr() if res else None, y.data_ptr(), bsz, c_in, h_in, pad, 1, stream)
+        if rc != 0:
+            raise RuntimeError("az_nn_othello_conv refused its arguments (%d)" % rc)
+        return y
+
+    @torch.no_grad()
+    def body(self, x, action_mask):
+        """(B, 3, 8, 8) planes + (B, 65) mask -> hidden (B, 10, 10, 256) NHWC bf16"""
+        net = self.net
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        mask = action_mask.view(torch.bool) if action_mask.dtype == torch.uint8 else action_mask.to(torch.bool)
+        t = net.embed(x.float(), mask).permute(0, 2, 3, 1).to(torch.bfloat16).contiguous()        # (B, 8, 8, 32)
+        h = self._conv(t, self.layers[0], None, s)
+        i = 1
+        while i < self.n_body - 1:
+            y1 = self._conv(h, self.layers[i], None, s)
+            h = self._conv(y1, self.layers[i + 1], h, s)
+            i += 2
+        return self._conv(h, self.layers[self.n_body - 1], None, s), s
+
+    @torch.no_grad()
+    def forward(self, x, action_mask=None):
+        """(log_prob (B, 65), log wdl (B, 3), aux (B,)) as the module's forward returns them"""
+        net = self.net
+        hidden, s = self.body(x, action_mask)
+        p = self._conv(hidden, self.layers[self.n_body], None, s)
+        p = self._conv(p, self.layers[self.n_body + 1], None, s)                                   # (B, 8, 8, 256)
+        pf = p.reshape(p.shape[0], 64, 256).float()
+        squares = pf @ self.board_w + self.board_b
+        ph = net.policy_head
+        skip = ph.pass_fc(ph.pass_norm(pf.mean(dim=1))).float()
+        log_prob = F.log_softmax(torch.cat([squares, skip], dim=1), dim=-1)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            value, aux = net.dual_head(hidden.permute(0, 3, 1, 2))
+        return log_prob, value.float(), aux.float()
+
+    @torch.no_grad()
+    def predict_device(self, x, action_mask=None):
+        log_prob, value, aux = self.forward(x, action_mask)
+        utility = torch.atan(aux * (float(self.aux_target_offset) / self.score_scale)) * (2.0 / math.pi)
+        return log_prob.exp().contiguous(), value.exp().contiguous(), utility.reshape(-1).contiguous()

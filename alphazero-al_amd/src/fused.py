@@ -153,11 +153,17 @@ class FusedSearch:
         if not self.use_fast or hasattr(self.net, "predict_device"):
             return
         from src.fast_net import FastConnect4Net
-        if not FastConnect4Net.recognises(self.net):
+        from src.fast_othello import FastOthelloNet
+        if self.game_name == "Othello" and FastOthelloNet.recognises(self.net):
+            make = lambda: FastOthelloNet(self.net)                                   # noqa: E731
+        elif self.game_name != "Othello" and FastConnect4Net.recognises(self.net):
+            make = lambda: FastConnect4Net.from_module(self.net, device=self.device)  # noqa: E731
+        else:
             return
-        version = tuple(p._version for p in self.net.parameters()) + tuple(p.data_ptr() for p in self.net.parameters())
+        version = (tuple(p._version for p in self.net.parameters()) + tuple(p.data_ptr() for p in self.net.parameters()) +
+                   tuple(b._version for b in self.net.buffers()))
         if self.fast is None or version != self._fast_version:
-            self.fast = FastConnect4Net.from_module(self.net, device=self.device)
+            self.fast = make()
             self._fast_version = version
             self._graphs.clear()        # captured graphs hold the old weight buffers
             self._eager_runs.clear()

@@ -124,6 +124,20 @@ int az_nn_model_forward(const az_nn_model *m, const float *features, const uint8
                         float *wdl, float *moves_left, int64_t batch, const int32_t *rows,
                         const int64_t *n_rows, void *scratch, uint64_t scratch_bytes, void *stream);
 
+/* One 3x3 convolution layer of the reference's Othello network (Othello/Network.py:22-66,129-139:
+ * 256 output channels on 10x10 / 8x8 maps) as an implicit-GEMM MFMA kernel (nn_othello.hip):
+ *   y = silu( post_scale * conv3x3( zero_pad( [pre_scale * x + pre_shift] ) ) + post_shift [+ residual] )
+ * x (batch, h_in, h_in, c_in) and y, residual (batch, h_out, h_out, 256) are NHWC bf16, h_out =
+ * h_in + 2 * pad - 2.  pre_* (c_in floats, both or neither): the BatchNorm in front of the
+ * convolution; post_* (256 floats, required: ones / zeros for none): the one behind it.
+ * w_packed: the (256, c_in, 3, 3) weight as bf16 in fragment order [tap][c_in / 32][channel tile 16]
+ * [lane 64 = 16 * k group + channel][8 input channels] (fast_othello.pack_conv_weight).
+ * Supported (c_in, h_in, pad): (32, 8, 2), (256, 10, 1) with or without pre / residual, (256, 10, 0),
+ * (256, 8, 1); apply_silu must be 1.  Returns 0, 1 on an unsupported combination. */
+int az_nn_othello_conv(const void *x, const void *w_packed, const float *pre_scale, const float *pre_shift,
+                       const float *post_scale, const float *post_shift, const void *residual, void *y,
+                       int64_t batch, int c_in, int h_in, int pad, int apply_silu, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

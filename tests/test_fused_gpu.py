@@ -803,3 +803,97 @@ def test_fused_othello_with_network(env):
         end = play[-1][0]
         own, opp = int(end[0].sum()), int(end[1].sum())
         assert winner == np.sign(own - opp) * int(end[2][0, 0]) and 4 < own + opp <= 64
+
+
+def _rand_othello_net(env, seed):
+    """OthelloNet at the reference's width with trained-looking BatchNorm statistics and non-zero heads"""
+    torch = env["torch"]
+    torch.manual_seed(seed)
+    net = env["N"].OthelloNet(device="cuda")
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0.0, 0.2); m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.7, 1.3); m.bias.normal_(0.0, 0.1)
+        for m in (net.policy_head.board_out, net.policy_head.pass_fc, net.dual_head.value_out[-1], net.dual_head.aux_out[-1]):
+            m.weight.normal_(0.0, 0.05); m.bias.normal_(0.0, 0.05)
+    return net
+
+
+def test_othello_conv_kernel_matches_torch(env):
+    """az_nn_othello_conv (nn_othello.hip) against the same layer in torch fp32 with the reference's
+    bf16 roundings, every supported geometry; batch sizes that leave workgroups with 0, 1 and
+    several samples."""
+    torch = env["torch"]
+    import ctypes as C
+    from src.fast_othello import pack_conv_weight
+    from src.fast_net import glue
+    L = glue()
+    vp = C.c_void_p
+    L.az_nn_othello_conv.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    F = torch.nn.functional
+    bf = lambda t: t.to(torch.bfloat16).float()                                   # noqa: E731
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    rn = lambda *sh: torch.randn(*sh, device="cuda", generator=g)                 # noqa: E731
+    for (cin, hi, pad, pre, res), bsz in (((32, 8, 2, False, False), 37), ((256, 10, 1, True, False), 5), ((256, 10, 1, True, True), 700),
+                                          ((256, 10, 1, False, False), 1), ((256, 10, 0, False, False), 130), ((256, 8, 1, False, False), 513)):
+        ho = hi + 2 * pad - 2
+        x = rn(bsz, hi, hi, cin).to(torch.bfloat16)
+        w = (rn(256, cin, 3, 3) * (1.5 / (9 * cin) ** 0.5))
+        pre_s, pre_b = (rn(cin) * 0.2 + 1.0, rn(cin) * 0.2) if pre else (None, None)
+        post_s, post_b = rn(256) * 0.2 + 1.0, rn(256) * 0.2
+        r = rn(bsz, ho, ho, 256).to(torch.bfloat16) if res else None
+        y = torch.empty((bsz, ho, ho, 256), dtype=torch.bfloat16, device="cuda")
+        wp = pack_conv_weight(w)
+        rc = L.az_nn_othello_conv(x.data_ptr(), wp.data_ptr(), pre_s.data_ptr() if pre else None, pre_b.data_ptr() if pre else None,
+                                  post_s.data_ptr(), post_b.data_ptr(), r.data_ptr() if res else None, y.data_ptr(), bsz, cin, hi, pad, 1,
+                                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
+        xin = x.float()
+        if pre:
+            xin = bf(xin * pre_s + pre_b)
+        conv = F.conv2d(xin.permute(0, 3, 1, 2), bf(w), padding=pad).permute(0, 2, 3, 1)
+        out = bf(conv * post_s + post_b)
+        if res:
+            out = bf(out + r.float())
+        want = bf(F.silu(out))
+        torch.cuda.synchronize()
+        err = (y.float() - want).abs()
+        assert err.max().item() < 0.06 and err.mean().item() < 2e-3, (cin, hi, pad, pre, res, err.max().item(), err.mean().item())
+    assert L.az_nn_othello_conv(x.data_ptr(), wp.data_ptr(), None, None, post_s.data_ptr(), post_b.data_ptr(), None, y.data_ptr(),
+                                4, 64, 8, 1, 1, None) == 1                       # unsupported geometry is refused
+
+
+def test_fast_othello_twin_matches_module(env):
+    """The HIP twin of the Othello network (fast_othello.py) against the module it snapshots, fp32 on
+    the GPU: probabilities, WDL and score utility within bf16 error; and the device loop picks it."""
+    torch = env["torch"]
+    from src.fast_othello import FastOthelloNet
+    net = _rand_othello_net(env, 3)
+    assert FastOthelloNet.recognises(net)
+    twin = FastOthelloNet(net)
+    rng = np.random.default_rng(8)
+    boards, turns = S.ot_openings(rng, 200, 40, 0)
+    planes = np.stack([(boards == turns[:, None, None]), (boards == -turns[:, None, None]),
+                       np.ones_like(boards) * turns[:, None, None]], 1).astype(np.float32)
+    masks = np.zeros((200, 65), bool)
+    for i in range(200):
+        mv = S.ot_moves(boards[i], int(turns[i]))
+        masks[i, mv if mv else [64]] = True
+    x = torch.from_numpy(planes).cuda(); m = torch.from_numpy(masks).cuda()
+    with torch.no_grad():
+        lp, lv, aux = net(x, m)
+    p0, w0 = lp.exp(), lv.exp()
+    u0 = torch.atan(aux * 8.0) * (2.0 / np.pi)
+    p1, w1, u1 = twin.predict_device(x, m)
+    torch.cuda.synchronize()
+    assert p1.shape == (200, 65) and w1.shape == (200, 3) and u1.shape == (200,)
+    assert (p1 - p0).abs().max().item() < 0.03 and (p1 - p0).abs().mean().item() < 1e-3
+    # the utility is atan(8 * aux): an error of the tanh head is amplified ~5x around zero
+    assert (w1 - w0).abs().max().item() < 0.06 and (u1 - u0).abs().max().item() < 0.15 and (u1 - u0).abs().mean().item() < 0.03
+    assert p0.std().item() > 1e-3 and w0.std().item() > 1e-2                      # the comparison is not between constants
+    w = env["W"].BatchedMCTS(200, 1.4, 800, 0.0, 40, noise_epsilon=0.0, fpu_reduction=0.2, use_symmetry=False,
+                             game_name="Othello", score_utility_factor=0.15, score_scale=8.0)
+    w.batch_playout(net, boards, turns, vl_batch=4, fused=True)
+    assert isinstance(w._fused.fast, FastOthelloNet)
+    assert (w.get_visits_count().sum(1) == 39).all()
