@@ -80,6 +80,19 @@ class FastOthelloNet(torch.nn.Module):
         ph = net.policy_head
         self.board_w = ph.board_out.weight.detach().float().reshape(256).contiguous()
         self.board_b = float(ph.board_out.bias.detach().float().item())
+        # The dual head's 8-channel bottleneck (3x3, no padding, 10x10 -> 8x8) has the geometry of the
+        # policy head's first convolution: it runs on the same kernel with its weight zero-padded to
+        # 256 output channels (library kernels take 7 ms for this layer at 16384 leaves, the padded
+        # launch 1.3 ms); only the first 8 channels of its output are read.
+        dh = net.dual_head
+        w8 = torch.zeros((256, 256, 3, 3), device=dev)
+        w8[:8] = dh.stem[0].weight.detach().float()
+        s8, b8 = _bn_affine(dh.stem[1])
+        post_s, post_b = ones.clone(), zeros.clone()
+        post_s[:8], post_b[:8] = s8.to(dev), b8.to(dev)
+        self.dual_stem = (pack_conv_weight(w8), None, (post_s, post_b), False, 256, 10, 0)
+        self.v_conv_w = dh.value_out[0].weight.detach().float().reshape(8, 72).t().contiguous()    # (72, 8)
+        self.v_bn = tuple(t.to(dev).view(1, 8, 1) for t in _bn_affine(dh.value_out[1]))
 
     def _conv(self, x, layer, residual, stream):
         wp, pre, post, res, c_in, h_in, pad = layer
@@ -120,8 +133,17 @@ class FastOthelloNet(torch.nn.Module):
         ph = net.policy_head
         skip = ph.pass_fc(ph.pass_norm(pf.mean(dim=1))).float()
         log_prob = F.log_softmax(torch.cat([squares, skip], dim=1), dim=-1)
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            value, aux = net.dual_head(hidden.permute(0, 3, 1, 2))
+        # dual head (Othello/Network.py:78-104) on the 8-channel bottleneck: a (B, 8, 8, 8) tensor
+        dh = net.dual_head
+        h8 = self._conv(hidden, self.dual_stem, None, s)[..., :8].permute(0, 3, 1, 2).float().contiguous()
+        # 3x3 stride-2 convolution 8 -> 8 on the 8x8 map as strided window views + one small GEMM (the
+        # library convolution and F.unfold both work sample by sample here)
+        win = h8.unfold(2, 3, 2).unfold(3, 3, 2)                                      # (B, c, oy, ox, ky, kx) view
+        v = (win.permute(0, 2, 3, 1, 4, 5).reshape(h8.shape[0], 9, 72) @ self.v_conv_w).transpose(1, 2)   # (B, 8, 9)
+        v = F.silu(v * self.v_bn[0] + self.v_bn[1])
+        value = F.log_softmax(dh.value_out[5](v.flatten(1)), dim=-1)
+        a = dh.aux_out[1](h8.flatten(1))
+        aux = torch.tanh(dh.aux_out[5](F.silu(dh.aux_out[2](a)))).squeeze(-1)
         return log_prob, value.float(), aux.float()
 
     @torch.no_grad()

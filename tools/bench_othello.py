@@ -1,8 +1,9 @@
 """BASELINE config 3: Othello, 4096 games, n_playout 400, virtual-loss batch 4,
 score utility 0.15, with the reference's Othello network (az_net.OthelloNet, h_dim 256, random
-init) as the evaluator.  The tree kernels and the games are the HIP engine's; the network runs as
-a torch module under bf16 autocast (MIOpen / hipBLASLt kernels) - no hand-written Othello
-evaluator exists yet.  Prints one JSON line.
+init) as the evaluator.  The tree kernels and the games are the HIP engine's; the network runs
+through its HIP twin (fast_othello.py: the 3x3 convolutions on nn_othello.hip) or, with
+AZ_FUSED_FASTNET=0, as the torch module under bf16 autocast (library kernels).  EVALUATOR=hash
+swaps in the integer-hash evaluator (tree kernels only).  Prints one JSON line.
 
     python tools/bench_othello.py [games] [n_playout] [timed_plies] [lead_in]
 """
@@ -53,8 +54,10 @@ def main():
                       "value": round(games * plies / el, 1), "unit": "positions/s", "ms_per_step": round(el / plies * 1e3, 1),
                       "sims_per_s": round(sims / el, 1), "node_expansions_per_s": round((c1["expansions"] - c0["expansions"]) / el, 1),
                       "mean_select_depth": round((c1["levels"] - c0["levels"]) / max(sims, 1), 3),
-                      "evaluator": ("OthelloNet h_dim 256, 3 residual blocks, random init, torch module under bf16 autocast (library kernels)"
-                                    if evaluator != "hash" else "integer-hash evaluator"),
+                      "evaluator": ("integer-hash evaluator" if evaluator == "hash" else
+                                    "OthelloNet h_dim 256, 3 residual blocks, random init, " +
+                                    ("HIP twin (nn_othello.hip convolutions)" if type(sp.fused.fast).__name__ == "FastOthelloNet"
+                                     else "torch module under bf16 autocast (library kernels)")),
                       "timed_plies": plies, "lead_in_plies": lead}), flush=True)
 
 
