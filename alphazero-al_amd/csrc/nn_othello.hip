@@ -80,18 +80,19 @@ __global__ void __launch_bounds__(256, 2) k_oth_conv(const uint16_t *x, const ui
         token = token < NT ? token : NT - 1;
         cell0[t] = (token / HO) * PW + (token % HO);
     }
-    // the pre-affine of the channel chunk this thread copies
-    float ps[8], pb[8];
-    if (PRE) {
-        const int c = tid % CPC;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { ps[j] = pre_s[c * 8 + j]; pb[j] = pre_b[c * 8 + j]; }
-    }
     const uint16_t *wlane = wp + static_cast<size_t>(wave * 4) * 512 + lane * 8;
 
     for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
         // ---- copy: sample -> zero-padded, swizzled image (the BatchNorm in front of the convolution rides here)
         const uint16_t *xs = x + b * (HI * HI * CIN);
+        // the pre-affine of the channel chunk this thread copies (loaded per sample: 16 registers that
+        // must not stay live through the MFMA phase)
+        float ps[8], pb[8];
+        if (PRE) {
+            const int c = tid % CPC;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { ps[j] = pre_s[c * 8 + j]; pb[j] = pre_b[c * 8 + j]; }
+        }
         for (int v = tid; v < PW * PW * CPC; v += 256) {
             const int cell = v / CPC, c = v % CPC;
             const int iy = cell / PW - PAD, ix = cell % PW - PAD;
@@ -115,29 +116,67 @@ __global__ void __launch_bounds__(256, 2) k_oth_conv(const uint16_t *x, const ui
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int t = 0; t < T; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        bf16x8 a_cur[4], a_nxt[4];
+        auto fetch_a = [&](bf16x8 (&a)[4], int ks) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a_cur[i] = *reinterpret_cast<const bf16x8 *>(wlane + i * 512);
-#pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {
-            const int tapcell = (tap / 3) * PW + (tap % 3);
+            for (int i = 0; i < 4; ++i)
+                a[i] = *reinterpret_cast<const bf16x8 *>(wlane + static_cast<size_t>(ks) * (16 * 512) + i * 512);
+        };
+        auto fetch_b = [&](bf16x8 (&bq)[T], int tapcell, int kc) {
 #pragma unroll
-            for (int kc = 0; kc < KPT; ++kc) {
-                const int ks = tap * KPT + kc;
-                const int nx = ks + 1 < KS ? ks + 1 : ks;             // the last step re-reads itself
+            for (int t = 0; t < T; ++t) {
+                const int p = cell0[t] + tapcell;
+                bq[t] = *reinterpret_cast<const bf16x8 *>(smem + p * CELLB + ((((kc << 2) | g) ^ (p & KEYM)) << 4));
+            }
+        };
+        auto multiply = [&](const bf16x8 (&a)[4], const bf16x8 (&bq)[T]) {
+#pragma unroll
+            for (int t = 0; t < T; ++t)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    a_nxt[i] = *reinterpret_cast<const bf16x8 *>(wlane + static_cast<size_t>(nx) * (16 * 512) + i * 512);
+                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bq[t], acc[i][t], 0, 0, 0);
+        };
+        if constexpr (KPT >= 2) {
+            // Software pipeline over k steps.  Weight fragments (L2, ~1 us away) of step k+1 are
+            // requested before the MFMAs of step k, into the other half of a register double
+            // buffer; a token fragment (LDS) of step k+1 is requested as soon as the four MFMAs
+            // that use its register in step k are issued - one whole step ahead of its use, with no
+            // second buffer.  The scheduling barriers keep the compiler from sinking the loads to
+            // their first use (left alone it does, and every k step waits out the L2 latency).
+            // KPT is even, so the halves of the A buffer are back in place at the loop edge.
+            bf16x8 a[2][4], bq[T];
+            fetch_a(a[0], 0);
+            fetch_b(bq, 0, 0);
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                const int tapcell = (tap / 3) * PW + (tap % 3);
+                const int ntap = tap < 8 ? tap + 1 : 8;
+                const int next_tapcell = (ntap / 3) * PW + (ntap % 3);
 #pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    const int p = cell0[t] + tapcell;
-                    const bf16x8 bv = *reinterpret_cast<const bf16x8 *>(smem + p * CELLB + ((((kc << 2) | g) ^ (p & KEYM)) << 4));
+                for (int kc = 0; kc < KPT; ++kc) {
+                    const int ks = tap * KPT + kc;
+                    fetch_a(a[(kc + 1) & 1], ks + 1 < KS ? ks + 1 : ks);                     // the last step re-reads itself
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int ncell = kc + 1 < KPT ? tapcell : next_tapcell;
+                    const int nkc = (kc + 1) % KPT;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur[i], bv, acc[i][t], 0, 0, 0);
+                    for (int t = 0; t < T; ++t) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kc & 1][i], bq[t], acc[i][t], 0, 0, 0);
+                        int p = cell0[t] + ncell;
+                        asm volatile("" : "+v"(p));          // recompute the address here: hoisted, the 8 x T offsets of a tap cost 56 registers
+                        bq[t] = *reinterpret_cast<const bf16x8 *>(smem + p * CELLB + ((((nkc << 2) | g) ^ (p & KEYM)) << 4));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) a_cur[i] = a_nxt[i];
+            }
+        } else {
+            bf16x8 a[4], bq[T];
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                fetch_a(a, tap);
+                fetch_b(bq, (tap / 3) * PW + (tap % 3), 0);
+                multiply(a, bq);
             }
         }
         __syncthreads();                       // every wavefront is done with the image

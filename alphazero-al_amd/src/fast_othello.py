@@ -78,7 +78,7 @@ class FastOthelloNet(torch.nn.Module):
         add(ps[0], None, _bn_affine(ps[1]), False, 256, 10, 0)
         add(ps[4], None, _bn_affine(ps[5]), False, 256, 8, 1)
         ph = net.policy_head
-        self.board_w = ph.board_out.weight.detach().float().reshape(256).contiguous()
+        self.board_w = ph.board_out.weight.detach().to(torch.bfloat16).reshape(256).contiguous()   # bf16, as under autocast
         self.board_b = float(ph.board_out.bias.detach().float().item())
         # The dual head's 8-channel bottleneck (3x3, no padding, 10x10 -> 8x8) has the geometry of the
         # policy head's first convolution: it runs on the same kernel with its weight zero-padded to
@@ -128,10 +128,10 @@ class FastOthelloNet(torch.nn.Module):
         hidden, s = self.body(x, action_mask)
         p = self._conv(hidden, self.layers[self.n_body], None, s)
         p = self._conv(p, self.layers[self.n_body + 1], None, s)                                   # (B, 8, 8, 256)
-        pf = p.reshape(p.shape[0], 64, 256).float()
-        squares = pf @ self.board_w + self.board_b
+        pf = p.reshape(p.shape[0], 64, 256)
+        squares = (pf @ self.board_w).float() + self.board_b                                       # the 1x1 convolution
         ph = net.policy_head
-        skip = ph.pass_fc(ph.pass_norm(pf.mean(dim=1))).float()
+        skip = ph.pass_fc(ph.pass_norm(pf.mean(dim=1, dtype=torch.float32))).float()
         log_prob = F.log_softmax(torch.cat([squares, skip], dim=1), dim=-1)
         # dual head (Othello/Network.py:78-104) on the 8-channel bottleneck: a (B, 8, 8, 8) tensor
         dh = net.dual_head
