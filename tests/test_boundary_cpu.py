@@ -89,6 +89,52 @@ def test_engine_fails_loudly_without_gpu(built):
         mcts_cpp.BatchedMCTS_Connect4(4)
 
 
+def test_evaluator_model_object_host_side(built):
+    """az_nn_model_* (include/az_nn.h) needs no device to be created: it is a bundle of pointers.
+    Creation validates its description, the scratch size is two bf16 activation tensors, and the
+    ctypes mirror of the struct (fast_net.ModelWeights) has the C layout (a wrong layout would put
+    n_blocks or eps where a pointer is expected and creation would refuse it or accept garbage)."""
+    from src.fast_net import ModelWeights, HeadsWeights, glue, MAX_BLOCKS
+    L = glue()
+    assert L is not None
+    fake = 0x1000                                     # any non-null address: nothing is dereferenced here
+    w = ModelWeights()
+    for n in ("emb_own", "emb_opp", "pos", "stem_w", "stem_b", "pre_w", "qkvg_w", "qn_w", "kn_w", "o_w"):
+        setattr(w, n, fake)
+    for n in HeadsWeights._PTRS:
+        setattr(w.heads, n, fake)
+    w.n_blocks = 3
+    for i in range(3):
+        for f in ("block_w", "block_b", "block_gamma", "block_beta"):
+            getattr(w, f)[i] = fake
+    w.eps = 1e-5
+    h = C.c_void_p()
+    assert L.az_nn_model_create(C.byref(w), C.byref(h)) == 0 and h.value
+    assert L.az_nn_model_scratch_bytes(h, 32768) == 2 * 32768 * 42 * 64 * 2
+    assert L.az_nn_model_scratch_bytes(h, 0) == 0
+    # forward refuses bad arguments before touching the device: no scratch, negative batch, rows without n_rows
+    assert L.az_nn_model_forward(h, fake, fake, fake, fake, fake, 8, None, None, None, 0, None) == 1
+    assert L.az_nn_model_forward(h, fake, fake, fake, fake, fake, -1, None, None, fake, 1 << 30, None) == 1
+    assert L.az_nn_model_forward(h, fake, fake, fake, fake, fake, 8, fake, None, fake, 1 << 30, None) == 1
+    assert L.az_nn_model_forward(h, fake, fake, fake, fake, fake, 0, None, None, None, 0, None) == 0      # empty batch: nothing to do
+    L.az_nn_model_destroy(h)
+    bad = ModelWeights.from_buffer_copy(w)
+    bad.n_blocks = MAX_BLOCKS + 1
+    assert L.az_nn_model_create(C.byref(bad), C.byref(h)) == 1
+    bad = ModelWeights.from_buffer_copy(w)
+    bad.block_gamma[2] = None
+    assert L.az_nn_model_create(C.byref(bad), C.byref(h)) == 1
+    bad = ModelWeights.from_buffer_copy(w)
+    bad.o_w = None
+    assert L.az_nn_model_create(C.byref(bad), C.byref(h)) == 1
+    assert L.az_nn_model_create(None, C.byref(h)) == 1
+    # the Othello convolution entry point refuses what it does not implement, without a device
+    L.az_nn_othello_conv.argtypes = [C.c_void_p] * 8 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    assert L.az_nn_othello_conv(fake, fake, None, None, fake, fake, None, fake, 4, 64, 8, 1, 1, None) == 1
+    assert L.az_nn_othello_conv(fake, fake, None, None, fake, fake, None, fake, 0, 256, 10, 1, 1, None) == 1
+    assert L.az_nn_othello_conv(fake, fake, fake, None, fake, fake, None, fake, 4, 256, 10, 1, 1, None) == 1
+
+
 def test_host_generator_matches_libstdcxx(built):
     g = load("rng_std")
     lib = C.CDLL(os.path.join(PKG, "lib", "libaz_mcts.so"))
@@ -362,3 +408,22 @@ def test_othello_network_port_matches_reference_outputs_g13(built):
     fresh = OthelloNet(h_dim=32, num_res_blocks=1)                            # zero heads: uniform outputs
     p, v, u = fresh.predict(planes[:4], masks[:4])
     assert np.allclose(p, 1 / 65, atol=1e-6) and np.allclose(v, 1 / 3, atol=1e-6) and np.allclose(u, 0, atol=1e-7)
+
+
+def test_othello_weight_packing_is_the_kernels_fragment_order(built):
+    """fast_othello.pack_conv_weight: element [tap][k chunk][channel tile][lane][j] must be
+    W[16 * tile + lane % 16, 32 * chunk + 8 * (lane // 16) + j, tap // 3, tap % 3] - what lane `lane`
+    of a wavefront feeds the MFMA as its A operand (nn_othello.hip)."""
+    import torch
+    from src.fast_othello import pack_conv_weight
+    torch.manual_seed(0)
+    for cin in (32, 256):
+        w = torch.randn(256, cin, 3, 3)
+        wp = pack_conv_weight(w).float()
+        assert wp.shape == (9, cin // 32, 16, 4, 16, 8) and wp.is_contiguous()
+        wb = w.to(torch.bfloat16).float()
+        rng = np.random.default_rng(cin)
+        for _ in range(200):
+            tap, kc, tile, lane, j = (int(rng.integers(0, n)) for n in (9, cin // 32, 16, 64, 8))
+            got = wp[tap, kc, tile, lane // 16, lane % 16, j]
+            assert got == wb[16 * tile + lane % 16, 32 * kc + 8 * (lane // 16) + j, tap // 3, tap % 3]
