@@ -93,20 +93,38 @@ __global__ void __launch_bounds__(256, 2) k_oth_conv(const uint16_t *x, const ui
 #pragma unroll
             for (int j = 0; j < 8; ++j) { ps[j] = pre_s[c * 8 + j]; pb[j] = pre_b[c * 8 + j]; }
         }
-        for (int v = tid; v < PW * PW * CPC; v += 256) {
-            const int cell = v / CPC, c = v % CPC;
-            const int iy = cell / PW - PAD, ix = cell % PW - PAD;
-            uint4 val = make_uint4(0u, 0u, 0u, 0u);
-            if (iy >= 0 && iy < HI && ix >= 0 && ix < HI) {
-                val = *reinterpret_cast<const uint4 *>(xs + (iy * HI + ix) * CIN + c * 8);
-                if (PRE) {
+        // loads in batches of six, then their arithmetic and LDS stores: as a rolled loop this phase is
+        // one global-load latency per iteration (18 of them per sample); all 18 at once cost 72 registers
+        constexpr int NV = PW * PW * CPC, ITERS = (NV + 255) / 256, BATCH = 6;
+        int ctid = tid;
+        asm volatile("" : "+v"(ctid));      // per-sample recomputation of the copy addresses: hoisted out of the sample loop they pin ~60 registers
+#pragma unroll
+        for (int base = 0; base < ITERS; base += BATCH) {
+            uint4 vals[BATCH];
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {
+                const int v = ctid + (base + k) * 256;
+                const int cell = v / CPC, c = v % CPC;
+                const int iy = cell / PW - PAD, ix = cell % PW - PAD;
+                vals[k] = make_uint4(0u, 0u, 0u, 0u);
+                if (base + k < ITERS && v < NV && iy >= 0 && iy < HI && ix >= 0 && ix < HI)
+                    vals[k] = *reinterpret_cast<const uint4 *>(xs + (iy * HI + ix) * CIN + c * 8);
+            }
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {
+                const int v = ctid + (base + k) * 256;
+                const int cell = v / CPC, c = v % CPC;
+                const int iy = cell / PW - PAD, ix = cell % PW - PAD;
+                uint4 val = vals[k];
+                if (PRE && iy >= 0 && iy < HI && ix >= 0 && ix < HI) {
                     uint32_t *wv = reinterpret_cast<uint32_t *>(&val);
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         wv[j] = pack2(bf_lo(wv[j]) * ps[2 * j] + pb[2 * j], bf_hi(wv[j]) * ps[2 * j + 1] + pb[2 * j + 1]);
                 }
+                if (base + k < ITERS && v < NV) *reinterpret_cast<uint4 *>(smem + cell * CELLB + ((c ^ (cell & KEYM)) << 4)) = val;
             }
-            *reinterpret_cast<uint4 *>(smem + cell * CELLB + ((c ^ (cell & KEYM)) << 4)) = val;
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
 
@@ -204,21 +222,39 @@ __global__ void __launch_bounds__(256, 2) k_oth_conv(const uint16_t *x, const ui
         // ---- coalesced pass: [+ residual] -> [SiLU] -> global
         uint16_t *ys = y + b * (NT * COUT);
         const uint16_t *rs = RES ? res + b * (NT * COUT) : nullptr;
-        for (int v = tid; v < NT * 32; v += 256) {
-            const int token = v >> 5, cc = v & 31;
-            uint4 val = *reinterpret_cast<const uint4 *>(smem + token * ROWB + ((cc ^ (token & 15)) << 4));
-            uint32_t *wv = reinterpret_cast<uint32_t *>(&val);
-            uint4 rv = make_uint4(0u, 0u, 0u, 0u);
-            if (RES) rv = *reinterpret_cast<const uint4 *>(rs + token * COUT + cc * 8);
-            const uint32_t *rw = reinterpret_cast<const uint32_t *>(&rv);
+        constexpr int OV = NT * 32, OITERS = (OV + 255) / 256, OBATCH = 7;
+        int otid = tid;
+        asm volatile("" : "+v"(otid));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float lo = bf_lo(wv[j]), hi = bf_hi(wv[j]);
-                if (RES) { lo = round_bf(lo + bf_lo(rw[j])); hi = round_bf(hi + bf_hi(rw[j])); }
-                if (SILU) { lo = silu(lo); hi = silu(hi); }
-                wv[j] = pack2(lo, hi);
+        for (int base = 0; base < OITERS; base += OBATCH) {
+            uint4 rvals[OBATCH];
+            if (RES) {
+#pragma unroll
+                for (int k = 0; k < OBATCH; ++k) {
+                    const int v = otid + (base + k) * 256;
+                    rvals[k] = make_uint4(0u, 0u, 0u, 0u);
+                    if (base + k < OITERS && v < OV) rvals[k] = *reinterpret_cast<const uint4 *>(rs + (v >> 5) * COUT + (v & 31) * 8);
+                }
             }
-            *reinterpret_cast<uint4 *>(ys + token * COUT + cc * 8) = val;
+#pragma unroll
+            for (int k = 0; k < OBATCH; ++k) {
+                const int v = otid + (base + k) * 256;
+                if (base + k < OITERS && v < OV) {
+                    const int token = v >> 5, cc = v & 31;
+                    uint4 val = *reinterpret_cast<const uint4 *>(smem + token * ROWB + ((cc ^ (token & 15)) << 4));
+                    uint32_t *wv = reinterpret_cast<uint32_t *>(&val);
+                    const uint32_t *rw = reinterpret_cast<const uint32_t *>(&rvals[k]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float lo = bf_lo(wv[j]), hi = bf_hi(wv[j]);
+                        if (RES) { lo = round_bf(lo + bf_lo(rw[j])); hi = round_bf(hi + bf_hi(rw[j])); }
+                        if (SILU) { lo = silu(lo); hi = silu(hi); }
+                        wv[j] = pack2(lo, hi);
+                    }
+                    *reinterpret_cast<uint4 *>(ys + token * COUT + cc * 8) = val;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();                       // the stage is the next sample's image
     }
