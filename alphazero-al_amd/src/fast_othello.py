@@ -74,6 +74,14 @@ class FastOthelloNet(torch.nn.Module):
             add(blk.conv2, _bn_affine(blk.norm2), None, True, 256, 10, 1)
         add(mods[3 + n_blocks], None, _bn_affine(mods[4 + n_blocks]), False, 256, 10, 1)
         self.n_body = len(self.layers)
+        # the embedding as one table lookup (Othello/Network.py:201-211): a cell shows its orbit's
+        # position vector plus exactly one of {own stone, opponent stone, empty + legal, empty + illegal}
+        with torch.no_grad():
+            pos = net.pos_emb(net.orbit_map).float()                                               # (64, 32)
+            kinds = torch.stack([net.piece_emb.weight[0], net.piece_emb.weight[1], net.legal_emb.weight[1],
+                                 net.legal_emb.weight[0]]).float()                                 # (4, 32)
+            self.embed_table = (pos[:, None, :] + kinds[None, :, :]).to(torch.bfloat16).reshape(256, 32).contiguous()
+        self.cell4 = (torch.arange(64, device=dev) * 4).view(1, 64)
         ps = net.policy_head.stem
         add(ps[0], None, _bn_affine(ps[1]), False, 256, 10, 0)
         add(ps[4], None, _bn_affine(ps[5]), False, 256, 8, 1)
@@ -112,7 +120,11 @@ class FastOthelloNet(torch.nn.Module):
         net = self.net
         s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         mask = action_mask.view(torch.bool) if action_mask.dtype == torch.uint8 else action_mask.to(torch.bool)
-        t = net.embed(x.float(), mask).permute(0, 2, 3, 1).to(torch.bfloat16).contiguous()        # (B, 8, 8, 32)
+        bsz = x.shape[0]
+        own = x[:, 0].reshape(bsz, 64) > 0.5
+        opp = x[:, 1].reshape(bsz, 64) > 0.5
+        kind = torch.where(own, 0, torch.where(opp, 1, torch.where(mask[:, :64], 2, 3)))
+        t = self.embed_table[(kind + self.cell4).reshape(-1)].view(bsz, 8, 8, 32)                  # NHWC bf16
         h = self._conv(t, self.layers[0], None, s)
         i = 1
         while i < self.n_body - 1:
