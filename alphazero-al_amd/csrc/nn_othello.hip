@@ -80,6 +80,11 @@ __global__ void __launch_bounds__(256, 2) k_oth_conv(const uint16_t *x, const ui
         token = token < NT ? token : NT - 1;
         cell0[t] = (token / HO) * PW + (token % HO);
     }
+    // Swizzle key of image cell (row, col): (row * HO + col) & KEYM.  A token's window cell under tap
+    // (ky, kx) then has key (token + HO * ky + kx) & KEYM: the 16 consecutive tokens of a tile read 16
+    // distinct bank slots under every tap (keyed by the padded cell index, tokens that wrap to the next
+    // image row collided with the first ones of the tile).  Only the clamped tail of the last tile repeats.
+    const int tl_last = ((T - 1) * 16 + tl < NT ? tl : NT - 1) & 15;
     const uint16_t *wlane = wp + static_cast<size_t>(wave * 4) * 512 + lane * 8;
 
     for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
@@ -122,7 +127,8 @@ __global__ void __launch_bounds__(256, 2) k_oth_conv(const uint16_t *x, const ui
                     for (int j = 0; j < 4; ++j)
                         wv[j] = pack2(bf_lo(wv[j]) * ps[2 * j] + pb[2 * j], bf_hi(wv[j]) * ps[2 * j + 1] + pb[2 * j + 1]);
                 }
-                if (base + k < ITERS && v < NV) *reinterpret_cast<uint4 *>(smem + cell * CELLB + ((c ^ (cell & KEYM)) << 4)) = val;
+                if (base + k < ITERS && v < NV)
+                    *reinterpret_cast<uint4 *>(smem + cell * CELLB + ((c ^ (((cell / PW) * HO + cell % PW) & KEYM)) << 4)) = val;
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -139,11 +145,12 @@ __global__ void __launch_bounds__(256, 2) k_oth_conv(const uint16_t *x, const ui
             for (int i = 0; i < 4; ++i)
                 a[i] = *reinterpret_cast<const bf16x8 *>(wlane + static_cast<size_t>(ks) * (16 * 512) + i * 512);
         };
-        auto fetch_b = [&](bf16x8 (&bq)[T], int tapcell, int kc) {
+        auto fetch_b = [&](bf16x8 (&bq)[T], int tapcell, int tapkey, int kc) {
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 const int p = cell0[t] + tapcell;
-                bq[t] = *reinterpret_cast<const bf16x8 *>(smem + p * CELLB + ((((kc << 2) | g) ^ (p & KEYM)) << 4));
+                const int key = ((t == T - 1 ? tl_last : tl) + tapkey) & KEYM;
+                bq[t] = *reinterpret_cast<const bf16x8 *>(smem + p * CELLB + ((((kc << 2) | g) ^ key) << 4));
             }
         };
         auto multiply = [&](const bf16x8 (&a)[4], const bf16x8 (&bq)[T]) {
@@ -163,18 +170,20 @@ __global__ void __launch_bounds__(256, 2) k_oth_conv(const uint16_t *x, const ui
             // KPT is even, so the halves of the A buffer are back in place at the loop edge.
             bf16x8 a[2][4], bq[T];
             fetch_a(a[0], 0);
-            fetch_b(bq, 0, 0);
+            fetch_b(bq, 0, 0, 0);
 #pragma unroll 1
             for (int tap = 0; tap < 9; ++tap) {
                 const int tapcell = (tap / 3) * PW + (tap % 3);
                 const int ntap = tap < 8 ? tap + 1 : 8;
                 const int next_tapcell = (ntap / 3) * PW + (ntap % 3);
+                const int tapkey = (tap / 3) * HO + (tap % 3), next_tapkey = (ntap / 3) * HO + (ntap % 3);
 #pragma unroll
                 for (int kc = 0; kc < KPT; ++kc) {
                     const int ks = tap * KPT + kc;
                     fetch_a(a[(kc + 1) & 1], ks + 1 < KS ? ks + 1 : ks);                     // the last step re-reads itself
                     __builtin_amdgcn_sched_barrier(0);
                     const int ncell = kc + 1 < KPT ? tapcell : next_tapcell;
+                    const int nkey = kc + 1 < KPT ? tapkey : next_tapkey;
                     const int nkc = (kc + 1) % KPT;
 #pragma unroll
                     for (int t = 0; t < T; ++t) {
@@ -183,7 +192,8 @@ __global__ void __launch_bounds__(256, 2) k_oth_conv(const uint16_t *x, const ui
                             acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kc & 1][i], bq[t], acc[i][t], 0, 0, 0);
                         int p = cell0[t] + ncell;
                         asm volatile("" : "+v"(p));          // recompute the address here: hoisted, the 8 x T offsets of a tap cost 56 registers
-                        bq[t] = *reinterpret_cast<const bf16x8 *>(smem + p * CELLB + ((((nkc << 2) | g) ^ (p & KEYM)) << 4));
+                        const int key = ((t == T - 1 ? tl_last : tl) + nkey) & KEYM;
+                        bq[t] = *reinterpret_cast<const bf16x8 *>(smem + p * CELLB + ((((nkc << 2) | g) ^ key) << 4));
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -193,7 +203,7 @@ __global__ void __launch_bounds__(256, 2) k_oth_conv(const uint16_t *x, const ui
 #pragma unroll 1
             for (int tap = 0; tap < 9; ++tap) {
                 fetch_a(a, tap);
-                fetch_b(bq, (tap / 3) * PW + (tap % 3), 0);
+                fetch_b(bq, (tap / 3) * PW + (tap % 3), (tap / 3) * HO + (tap % 3), 0);
                 multiply(a, bq);
             }
         }
