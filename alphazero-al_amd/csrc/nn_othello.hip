@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "az_nn.h"
 
@@ -54,7 +55,7 @@ __device__ __forceinline__ float silu(float v) { return __fdividef(v, 1.0f + __e
 template <int CIN, int HI, int PAD, bool PRE, bool RES, bool SILU>
 __global__ void __launch_bounds__(256, 2) k_oth_conv(const uint16_t *x, const uint16_t *wp, const float *pre_s,
                                                      const float *pre_b, const float *post_s, const float *post_b,
-                                                     const uint16_t *res, uint16_t *y, int64_t B)
+                                                     const uint16_t *res, uint16_t *y, int64_t B, int dbg)
 {
     constexpr int PW = HI + 2 * PAD;          // padded width
     constexpr int HO = PW - 2;                // output width
@@ -141,6 +142,7 @@ __global__ void __launch_bounds__(256, 2) k_oth_conv(const uint16_t *x, const ui
 #pragma unroll
             for (int t = 0; t < T; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
         auto fetch_a = [&](bf16x8 (&a)[4], int ks) {
+            if (dbg & 1) ks &= 1;       // timing experiment (AZ_OTH_DEBUG=1, results wrong): the weight stream stays in L1
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 a[i] = *reinterpret_cast<const bf16x8 *>(wlane + static_cast<size_t>(ks) * (16 * 512) + i * 512);
@@ -284,10 +286,11 @@ int launch(const void *x, const void *wp, const float *pre_s, const float *pre_b
             return 2;
         attr_set = true;
     }
+    static const int dbg = getenv("AZ_OTH_DEBUG") ? atoi(getenv("AZ_OTH_DEBUG")) : 0;
     const unsigned grid = static_cast<unsigned>(B < 512 ? B : 512);      // two workgroups per CU, persistent over samples
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), SMEM, s, static_cast<const uint16_t *>(x),
                        static_cast<const uint16_t *>(wp), pre_s, pre_b, post_s, post_b,
-                       static_cast<const uint16_t *>(res), static_cast<uint16_t *>(y), B);
+                       static_cast<const uint16_t *>(res), static_cast<uint16_t *>(y), B, dbg);
     return 0;
 }
 
