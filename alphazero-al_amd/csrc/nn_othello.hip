@@ -294,6 +294,70 @@ int launch(const void *x, const void *wp, const float *pre_s, const float *pre_b
     return 0;
 }
 
+// The dual head's bottleneck (Othello/Network.py:81-83): 3x3, NO padding, 256 -> 8 channels on the
+// 10x10 map -> (8, 8, 8), BatchNorm, SiLU.  One channel tile (8 real channels + 8 of zero weight), so
+// the four wavefronts of a sample's workgroup split its four TOKEN tiles instead; the weights (72 KB
+// in fragment order) are the same lines for every wavefront and stay in L1.  The kernel is bound by
+// the copy of the sample into LDS, not by its 72 MFMAs per wavefront.
+__global__ void __launch_bounds__(256, 2) k_oth_conv_narrow(const uint16_t *x, const uint16_t *wp, const float *post_s,
+                                                            const float *post_b, uint16_t *y, int64_t B)
+{
+    constexpr int CIN = 256, HI = 10, PW = 10, HO = 8, NT = 64, CELLB = CIN * 2, CPC = 32, KPT = 8;
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, tl = lane & 15;
+    const int token = wave * 16 + tl;
+    const int cell0 = (token / HO) * PW + (token % HO);
+    const f32x4 s4 = *reinterpret_cast<const f32x4 *>(post_s + g * 4);
+    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(post_b + g * 4);
+    for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+        const uint16_t *xs = x + b * (HI * HI * CIN);
+        constexpr int NV = PW * PW * CPC, ITERS = (NV + 255) / 256;         // 3200 chunks: 12.5 per thread
+        int ctid = tid;
+        asm volatile("" : "+v"(ctid));
+#pragma unroll
+        for (int base = 0; base < ITERS; base += 7) {
+            uint4 vals[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                const int v = ctid + (base + k) * 256;
+                vals[k] = make_uint4(0u, 0u, 0u, 0u);
+                if (base + k < ITERS && v < NV) vals[k] = *reinterpret_cast<const uint4 *>(xs + v * 8);
+            }
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                const int v = ctid + (base + k) * 256;
+                const int cell = v / CPC, c = v % CPC;
+                if (base + k < ITERS && v < NV)
+                    *reinterpret_cast<uint4 *>(smem + cell * CELLB + ((c ^ (((cell / PW) * HO + cell % PW) & 15)) << 4)) = vals[k];
+            }
+        }
+        __syncthreads();
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int p = cell0 + (tap / 3) * PW + (tap % 3);
+            const int key = (tl + (tap / 3) * HO + (tap % 3)) & 15;
+            bf16x8 a[KPT], bv[KPT];
+#pragma unroll
+            for (int kc = 0; kc < KPT; ++kc) {
+                a[kc] = *reinterpret_cast<const bf16x8 *>(wp + static_cast<size_t>(tap * KPT + kc) * 512 + lane * 8);
+                bv[kc] = *reinterpret_cast<const bf16x8 *>(smem + p * CELLB + ((((kc << 2) | g) ^ key) << 4));
+            }
+#pragma unroll
+            for (int kc = 0; kc < KPT; ++kc) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kc], bv[kc], acc, 0, 0, 0);
+        }
+        if (g < 2) {                                 // channels 0..7 live in the lanes of k groups 0 and 1
+            const f32x4 v = acc * s4 + b4;
+            uint2 o;
+            o.x = pack2(silu(round_bf(v[0])), silu(round_bf(v[1])));
+            o.y = pack2(silu(round_bf(v[2])), silu(round_bf(v[3])));
+            *reinterpret_cast<uint2 *>(y + (b * NT + token) * 8 + g * 4) = o;
+        }
+        __syncthreads();                             // the image is rewritten for the next sample
+    }
+}
+
 }  // namespace
 
 extern "C" int az_nn_othello_conv(const void *x, const void *w_packed, const float *pre_scale, const float *pre_shift,
@@ -315,4 +379,23 @@ extern "C" int az_nn_othello_conv(const void *x, const void *w_packed, const flo
     if (c_in == 256 && h_in == 8 && pad == 1 && !pre && !res && apply_silu) AZ_OTH(256, 8, 1, false, false, true);
 #undef AZ_OTH
     return 1;
+}
+
+extern "C" int az_nn_othello_conv_narrow(const void *x, const void *w_packed16, const float *post_scale16,
+                                         const float *post_shift16, void *y, int64_t batch, void *stream)
+{
+    if (batch <= 0 || x == nullptr || w_packed16 == nullptr || y == nullptr || post_scale16 == nullptr || post_shift16 == nullptr)
+        return 1;
+    constexpr int SMEM = 100 * 512;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_oth_conv_narrow), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
+            return 2;
+        attr_set = true;
+    }
+    const unsigned grid = static_cast<unsigned>(batch < 768 ? batch : 768);       // three workgroups per CU
+    hipLaunchKernelGGL(k_oth_conv_narrow, dim3(grid), dim3(256), SMEM, static_cast<hipStream_t>(stream),
+                       static_cast<const uint16_t *>(x), static_cast<const uint16_t *>(w_packed16), post_scale16, post_shift16,
+                       static_cast<uint16_t *>(y), batch);
+    return 0;
 }

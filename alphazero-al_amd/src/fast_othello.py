@@ -28,8 +28,8 @@ def pack_conv_weight(w):
     """(256, C_in, 3, 3) -> bf16 in the kernel's A-fragment order [tap][k chunk of 32][channel tile]
     [lane = 16 * k group + channel][8 consecutive input channels]."""
     co, ci = w.shape[0], w.shape[1]
-    assert co == 256 and ci % 32 == 0 and tuple(w.shape[2:]) == (3, 3)
-    t = w.detach().to(torch.bfloat16).permute(2, 3, 1, 0).reshape(9, ci // 32, 4, 8, 16, 16)   # tap, kc, g, j, tile, tl
+    assert co % 16 == 0 and ci % 32 == 0 and tuple(w.shape[2:]) == (3, 3)
+    t = w.detach().to(torch.bfloat16).permute(2, 3, 1, 0).reshape(9, ci // 32, 4, 8, co // 16, 16)   # tap, kc, g, j, tile, tl
     return t.permute(0, 1, 4, 2, 5, 3).contiguous()
 
 
@@ -88,17 +88,16 @@ class FastOthelloNet(torch.nn.Module):
         ph = net.policy_head
         self.board_w = ph.board_out.weight.detach().to(torch.bfloat16).reshape(256).contiguous()   # bf16, as under autocast
         self.board_b = float(ph.board_out.bias.detach().float().item())
-        # The dual head's 8-channel bottleneck (3x3, no padding, 10x10 -> 8x8) has the geometry of the
-        # policy head's first convolution: it runs on the same kernel with its weight zero-padded to
-        # 256 output channels (library kernels take 7 ms for this layer at 16384 leaves, the padded
-        # launch 1.3 ms); only the first 8 channels of its output are read.
+        # the dual head's 8-channel bottleneck (3x3, no padding, 10x10 -> 8x8): its own narrow kernel
         dh = net.dual_head
-        w8 = torch.zeros((256, 256, 3, 3), device=dev)
-        w8[:8] = dh.stem[0].weight.detach().float()
+        w16 = torch.zeros((16, 256, 3, 3), device=dev)
+        w16[:8] = dh.stem[0].weight.detach().float()
         s8, b8 = _bn_affine(dh.stem[1])
-        post_s, post_b = ones.clone(), zeros.clone()
-        post_s[:8], post_b[:8] = s8.to(dev), b8.to(dev)
-        self.dual_stem = (pack_conv_weight(w8), None, (post_s, post_b), False, 256, 10, 0)
+        self.dual_w = pack_conv_weight(w16)
+        self.dual_s = torch.ones(16, device=dev)
+        self.dual_b = torch.zeros(16, device=dev)
+        self.dual_s[:8], self.dual_b[:8] = s8.to(dev), b8.to(dev)
+        L.az_nn_othello_conv_narrow.argtypes = [vp, vp, vp, vp, vp, i64, vp]
         self.v_conv_w = dh.value_out[0].weight.detach().float().reshape(8, 72).t().contiguous()    # (72, 8)
         self.v_bn = tuple(t.to(dev).view(1, 8, 1) for t in _bn_affine(dh.value_out[1]))
 
@@ -147,7 +146,11 @@ class FastOthelloNet(torch.nn.Module):
         log_prob = F.log_softmax(torch.cat([squares, skip], dim=1), dim=-1)
         # dual head (Othello/Network.py:78-104) on the 8-channel bottleneck: a (B, 8, 8, 8) tensor
         dh = net.dual_head
-        h8 = self._conv(hidden, self.dual_stem, None, s)[..., :8].permute(0, 3, 1, 2).float().contiguous()
+        h8 = torch.empty((hidden.shape[0], 8, 8, 8), dtype=torch.bfloat16, device=self.device)
+        if self._L.az_nn_othello_conv_narrow(hidden.data_ptr(), self.dual_w.data_ptr(), self.dual_s.data_ptr(),
+                                             self.dual_b.data_ptr(), h8.data_ptr(), hidden.shape[0], s) != 0:
+            raise RuntimeError("az_nn_othello_conv_narrow refused its arguments")
+        h8 = h8.permute(0, 3, 1, 2).float().contiguous()                                            # (B, 8 channels, 8, 8)
         # 3x3 stride-2 convolution 8 -> 8 on the 8x8 map as strided window views + one small GEMM (the
         # library convolution and F.unfold both work sample by sample here)
         win = h8.unfold(2, 3, 2).unfold(3, 3, 2)                                      # (B, c, oy, ox, ky, kx) view

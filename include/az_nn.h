@@ -138,6 +138,13 @@ int az_nn_othello_conv(const void *x, const void *w_packed, const float *pre_sca
                        const float *post_scale, const float *post_shift, const void *residual, void *y,
                        int64_t batch, int c_in, int h_in, int pad, int apply_silu, void *stream);
 
+/* The dual head's 8-channel bottleneck of the same network (Othello/Network.py:81-83): 3x3, no padding,
+ * 256 -> 8 channels on the 10x10 map, BatchNorm, SiLU.  x (batch, 10, 10, 256) NHWC bf16 -> y (batch, 8, 8, 8)
+ * NHWC bf16.  w_packed16: the (8, 256, 3, 3) weight padded with zeros to 16 output channels, packed like
+ * az_nn_othello_conv's with ONE channel tile; post_*16: 16 floats each (entries 8..15 unused). */
+int az_nn_othello_conv_narrow(const void *x, const void *w_packed16, const float *post_scale16,
+                              const float *post_shift16, void *y, int64_t batch, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

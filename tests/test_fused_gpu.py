@@ -862,6 +862,22 @@ def test_othello_conv_kernel_matches_torch(env):
         assert err.max().item() < 0.06 and err.mean().item() < 2e-3, (cin, hi, pad, pre, res, err.max().item(), err.mean().item())
     assert L.az_nn_othello_conv(x.data_ptr(), wp.data_ptr(), None, None, post_s.data_ptr(), post_b.data_ptr(), None, y.data_ptr(),
                                 4, 64, 8, 1, 1, None) == 1                       # unsupported geometry is refused
+    # the narrow kernel of the dual head's bottleneck: 256 -> 8 channels, no padding
+    L.az_nn_othello_conv_narrow.argtypes = [vp, vp, vp, vp, vp, C.c_int64, vp]
+    for bsz in (3, 1000):
+        x = rn(bsz, 10, 10, 256).to(torch.bfloat16)
+        w = rn(8, 256, 3, 3) * (1.5 / 2304 ** 0.5)
+        w16 = torch.zeros(16, 256, 3, 3, device="cuda"); w16[:8] = w
+        s16, b16 = torch.ones(16, device="cuda"), torch.zeros(16, device="cuda")
+        s16[:8], b16[:8] = rn(8) * 0.2 + 1.0, rn(8) * 0.2
+        y = torch.full((bsz, 8, 8, 8), 7.0, dtype=torch.bfloat16, device="cuda")
+        assert L.az_nn_othello_conv_narrow(x.data_ptr(), pack_conv_weight(w16).data_ptr(), s16.data_ptr(), b16.data_ptr(), y.data_ptr(),
+                                           bsz, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+        conv = F.conv2d(x.float().permute(0, 3, 1, 2), bf(w)).permute(0, 2, 3, 1)
+        want = bf(F.silu(bf(conv * s16[:8] + b16[:8])))
+        torch.cuda.synchronize()
+        err = (y.float() - want).abs()
+        assert err.max().item() < 0.06 and err.mean().item() < 2e-3, (bsz, err.max().item(), err.mean().item())
 
 
 def test_fast_othello_twin_matches_module(env):
