@@ -215,7 +215,7 @@ def main():
     else:
         net = Connect4Net(device=dev).eval()
     sp = StreamedSelfPlay(net, args.games, streams=args.streams, n_playout=args.n_playout, vl_batch=args.vl_batch,
-                          seed=rank, reserve_slots=int(os.environ.get("AZ_RESERVE_SLOTS", "49152")),
+                          seed=rank, reserve_slots=int(os.environ["AZ_RESERVE_SLOTS"]) if "AZ_RESERVE_SLOTS" in os.environ else None,
                           table_log2=args.table)
     handles = [part.h for part in sp.parts]
     L = F.lib()
