@@ -164,7 +164,7 @@ class FastConnect4Net(torch.nn.Module):
         one C call, what az_mcts_dev_search runs inside its loop.  None when the all-HIP path is off."""
         if not self.supports_compact or not self.fused_stem or len(self.res) > MAX_BLOCKS:
             return None
-        if getattr(self, "_model", None) is None:
+        if self.__dict__.get("_model") is None:
             w = ModelWeights()
             for n in ("emb_own", "emb_opp", "pos", "stem_w", "stem_b", "pre_w", "qkvg_w", "qn_w", "kn_w", "o_w"):
                 setattr(w, n, getattr(self, n).data_ptr())
@@ -177,14 +177,18 @@ class FastConnect4Net(torch.nn.Module):
             h = C.c_void_p()
             if glue().az_nn_model_create(C.byref(w), C.byref(h)) != 0:
                 raise RuntimeError("az_nn_model_create refused the weights")
-            self._model = h
-        return self._model
+            self.__dict__["_model"] = h
+        return self.__dict__["_model"]
 
     def __del__(self):
-        h = getattr(self, "_model", None)
-        if h is not None and _GLUE:
-            _GLUE.az_nn_model_destroy(h)
-            self._model = None
+        # may run while the interpreter is being torn down: no nn.Module machinery, no exceptions
+        try:
+            h = self.__dict__.get("_model")
+            if h is not None and _GLUE:
+                self.__dict__["_model"] = None
+                _GLUE.az_nn_model_destroy(h)
+        except Exception:
+            pass
 
     @classmethod
     def from_module(cls, net, dtype=torch.bfloat16, device=None):

@@ -21,7 +21,7 @@ table = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 torch.manual_seed(0)
 net = Connect4Net(device="cuda").eval()
 sp = DeviceSelfPlay(net, 8192, n_playout=200, vl_batch=4, seed=0, record=True, td_steps=2, table_log2=table,
-                    reserve_slots=49152, max_finished_games=65536)
+                    max_finished_games=65536)
 t0 = time.perf_counter()
 tl = t0
 for i in range(steps):
