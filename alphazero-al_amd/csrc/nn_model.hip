@@ -8,7 +8,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <mutex>
 #include <new>
+#include <vector>
 
 #include "az_nn.h"
 
@@ -18,6 +20,18 @@ struct az_nn_model {
 
 namespace {
 constexpr int64_t kTokenBytes = 42 * 64 * 2;     // one sample's (42, 64) bf16 activations
+
+// az_nn_model_profile: event pairs around the FIRST residual block of every stride-th forward call
+// (process-wide; the mutex only matters when several streams share the model)
+struct Profile {
+    std::mutex mu;
+    bool on = false;
+    int stride = 1;
+    int64_t seen = 0;
+    std::vector<hipEvent_t> start, stop;
+    size_t used = 0;
+} g_prof;
+constexpr size_t kProfileMax = 4096;
 }
 
 extern "C" {
@@ -59,8 +73,19 @@ int az_nn_model_forward(const az_nn_model *m, const float *features, const uint8
     char *b = a + batch * kTokenBytes;
     int rc = az_nn_stem_embed(features, w.emb_own, w.emb_opp, w.pos, w.stem_w, w.stem_b, a, batch, rows, n_rows, stream);
     for (int i = 0; rc == 0 && i < w.n_blocks; ++i) {
+        int slot = -1;
+        if (i == 0 && g_prof.on) {
+            std::lock_guard<std::mutex> lk(g_prof.mu);
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            const bool capturing = hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+            if (g_prof.on && !capturing && (g_prof.seen++ % g_prof.stride) == 0 && g_prof.used < g_prof.start.size()) {
+                slot = static_cast<int>(g_prof.used++);
+                (void)hipEventRecord(g_prof.start[slot], static_cast<hipStream_t>(stream));
+            }
+        }
         rc = az_nn_conv_block(a, 64, w.block_w[i], w.block_b[i], w.block_gamma[i], w.block_beta[i], 1, b, batch,
                               w.eps, n_rows, stream);
+        if (slot >= 0) (void)hipEventRecord(g_prof.stop[slot], static_cast<hipStream_t>(stream));
         char *t = a; a = b; b = t;
     }
     if (rc == 0) {
@@ -70,6 +95,39 @@ int az_nn_model_forward(const az_nn_model *m, const float *features, const uint8
     if (rc == 0)
         rc = az_nn_heads(a, &w.heads, mask, probs, wdl, moves_left, batch, w.eps, rows, n_rows, stream);
     return rc;
+}
+
+int az_nn_model_profile(int enable)
+{
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    if (enable) {
+        while (g_prof.start.size() < kProfileMax) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return 2;
+            g_prof.start.push_back(a); g_prof.stop.push_back(b);
+        }
+    }
+    g_prof.on = enable != 0;
+    g_prof.stride = enable > 1 ? enable : 1;
+    g_prof.seen = 0;
+    return 0;
+}
+
+int az_nn_model_profile_read(double *out_ms, int64_t *out_launches)
+{
+    if (out_ms == nullptr || out_launches == nullptr) return 1;
+    if (hipDeviceSynchronize() != hipSuccess) return 2;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    double ms = 0.0;
+    for (size_t i = 0; i < g_prof.used; ++i) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g_prof.start[i], g_prof.stop[i]) != hipSuccess) return 2;
+        ms += t;
+    }
+    *out_ms = ms;
+    *out_launches = static_cast<int64_t>(g_prof.used);
+    g_prof.used = 0;
+    return 0;
 }
 
 }  // extern "C"

@@ -234,6 +234,12 @@ def main():
     for h in handles:
         F.check(L.az_mcts_counters_reset(h))
         F.check(L.az_mcts_profile(h, PROFILE_EVERY))      # every 4th selection / backup launch carries an event pair
+    import ctypes as C
+    from src.fast_net import glue
+    G = glue()
+    G.az_nn_model_profile.argtypes = [C.c_int]
+    G.az_nn_model_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    G.az_nn_model_profile(PROFILE_EVERY)                   # and every 4th first residual block of the evaluator
     t_before = sp.read_totals()
 
     if world > 1:
@@ -248,7 +254,9 @@ def main():
     elapsed = time.perf_counter() - t0
     log(f"timed region: {args.steps} steps in {elapsed:.2f} s")
 
-    import ctypes as C
+    conv_ms, conv_n = C.c_double(), C.c_int64()
+    G.az_nn_model_profile_read(C.byref(conv_ms), C.byref(conv_n))
+    G.az_nn_model_profile(0)
     ms = [0.0, 0.0]; nl = [0, 0]
     for h in handles:
         ms_h = (C.c_double * 2)(); nl_h = (C.c_int64 * 2)()
@@ -335,7 +343,27 @@ def main():
         }
         fast = sp.parts[0].fused.fast
         if args.evaluator == "cnn" and fast is not None and getattr(fast, "mfma_conv", False):
-            out["roofline_evaluator"] = conv_roofline(torch, fast, args.games * args.vl_batch // max(args.streams, 1))
+            synth = conv_roofline(torch, fast, args.games * args.vl_batch // max(args.streams, 1))
+            if conv_n.value > 0:
+                # measured on launches of the timed region: the evaluator sees the non-terminal leaves only
+                live = (cnt["sims"] - cnt["terminal"]) / max(cnt["select_launches"], 1)
+                raw_us = conv_ms.value / conv_n.value * 1e3
+                us = max(raw_us - (roofline["empty_event_pair_us"] if roofline else 0.0), raw_us * 0.25)
+                flops = 2.0 * 42 * 64 * 576 * live
+                ach = flops / (us * 1e-6) / 1e12
+                out["roofline_evaluator"] = {
+                    "bound": "mfma", "kernel": "k_conv_block<64,norm,residual> (3 of the 6 evaluator launches, ~43 % of a step)",
+                    "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
+                    "avg_launch_us": round(us, 1), "launches_timed": int(conv_n.value), "leaves_per_launch": round(live, 1),
+                    "flops_per_launch": int(flops), "traffic": int(2 * live * 42 * 64 * 2),
+                    "note": "HIP events around every %d-th first residual block inside the timed region (az_nn_model_profile), "
+                            "event-pair overhead removed; dense bf16 MFMA peak; the kernel's HBM traffic equals its algorithmic "
+                            "bytes (profiles/r01_pmc_fetch_write_by_kernel_final.csv)" % PROFILE_EVERY,
+                    "synthetic_launch": {"achieved": synth["achieved"], "avg_launch_us": synth["avg_launch_us"],
+                                         "leaves": args.games * args.vl_batch // max(args.streams, 1),
+                                         "note": "same kernel on random activations after the run: slower, the clock follows the data"}}
+            else:
+                out["roofline_evaluator"] = synth
         if args.table:
             st = sp.table_stats()                        # whole run, warm-up included
             out["config"]["workload"] += ", transposition table 2^%d entries" % args.table

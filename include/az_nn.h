@@ -123,6 +123,13 @@ uint64_t az_nn_model_scratch_bytes(const az_nn_model *m, int64_t batch);
 int az_nn_model_forward(const az_nn_model *m, const float *features, const uint8_t *mask, float *probs,
                         float *wdl, float *moves_left, int64_t batch, const int32_t *rows,
                         const int64_t *n_rows, void *scratch, uint64_t scratch_bytes, void *stream);
+/* Kernel timing inside az_nn_model_forward (bench.py's roofline of the evaluator, measured on the
+ * launches of the timed region instead of a synthetic one): enable = n >= 1 puts a HIP event pair
+ * around the FIRST residual convolution block of every n-th forward call (process-wide, at most
+ * 4096 pairs between reads; not while the stream is capturing); az_nn_model_profile_read
+ * synchronises the device and returns the summed milliseconds and the number of launches summed. */
+int az_nn_model_profile(int enable);
+int az_nn_model_profile_read(double *out_ms, int64_t *out_launches);
 
 /* One 3x3 convolution layer of the reference's Othello network (Othello/Network.py:22-66,129-139:
  * 256 output channels on 10x10 / 8x8 maps) as an implicit-GEMM MFMA kernel (nn_othello.hip):
