@@ -913,3 +913,33 @@ def test_fast_othello_twin_matches_module(env):
     w.batch_playout(net, boards, turns, vl_batch=4, fused=True)
     assert isinstance(w._fused.fast, FastOthelloNet)
     assert (w.get_visits_count().sum(1) == 39).all()
+
+
+def test_native_search_refuses_misuse_and_reservation_is_sized(env):
+    """az_mcts_dev_search reports misuse through the error code / az_last_error (no evaluator, an
+    Othello engine, a table that was never created); the self-play driver reserves the arena for the
+    longest game up front (the engine never compacts a tree during a game)."""
+    torch = env["torch"]
+    F = env["F"]
+    L = F.lib()
+    L.az_last_error.restype = F.C.c_char_p
+    w = env["W"].BatchedMCTS(600, 1.4, 400, 0.3, 16)
+    h = F.C.c_void_p(w.mcts.handle)
+    s = F._stream()
+    assert L.az_mcts_dev_search(h, None, 16, 4, 0, s) != 0 and b"model" in L.az_last_error()
+    wts = load("g7_checkpoint_weights")
+    net = env["N"].Connect4Net(device="cuda").eval()
+    env["N"].load_reference_weights(net, {k: wts[k] for k in wts.files})
+    from src.fast_net import FastConnect4Net
+    model = FastConnect4Net.from_module(net).native_model()
+    assert model is not None
+    assert L.az_mcts_dev_search(h, model, 16, 4, 1, s) != 0 and b"table" in L.az_last_error()
+    assert L.az_mcts_dev_search(h, model, 16, 0, 0, s) != 0
+    wo = env["W"].BatchedMCTS(64, 1.4, 400, 0.3, 16, game_name="Othello")
+    assert L.az_mcts_dev_search(F.C.c_void_p(wo.mcts.handle), model, 16, 4, 0, s) != 0 and b"Connect4" in L.az_last_error()
+    assert L.az_mcts_dev_search(h, model, 0, 4, 0, s) == 0                      # nothing to do is not an error
+    torch.cuda.synchronize()
+    sp = env["SP"].DeviceSelfPlay(env["H"].HashEvaluator("cuda"), 512, n_playout=100, vl_batch=4)
+    assert L.az_mcts_capacity(sp.h) >= 100 * 7 * 42
+    sp = env["SP"].DeviceSelfPlay(env["H"].HashEvaluator("cuda"), 64, n_playout=40, vl_batch=4, reserve_slots=5000)
+    assert L.az_mcts_capacity(sp.h) == 5000
