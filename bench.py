@@ -306,11 +306,24 @@ def main():
                     traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
+            # achievable copy bandwidth on this box (SURVEY 8d asks for it beside the datasheet peak)
+            src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+            dst = torch.empty_like(src)
+            dst.copy_(src)
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            for _ in range(5):
+                dst.copy_(src)
+            c1.record()
+            torch.cuda.synchronize()
+            copy_gbs = 5 * 2 * (1 << 30) / (c0.elapsed_time(c1) * 1e-3) / 1e9
+            del src, dst
             roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                         "kernel": "k_select<VL>", "avg_launch_us": round(avg_ms * 1e3, 2),
                         "avg_event_pair_us": round(raw_ms * 1e3, 2), "empty_event_pair_us": round(pair_ms * 1e3, 2),
                         "launches_timed": sel_n, "algorithmic_bytes_per_launch": int(per_launch_bytes),
+                        "measured_copy_GBs": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 6),
                         "trees_per_launch": args.games // max(args.streams, 1), "concurrent_streams": args.streams}
             if args.streams > 1:
                 roofline["note"] = ("%d drivers on separate streams: a launch covers %d trees and shares the chip with the "
