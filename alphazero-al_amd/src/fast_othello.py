@@ -60,7 +60,6 @@ class FastOthelloNet(torch.nn.Module):
         mods = list(net.stem)
         n_blocks = sum(1 for m in mods if hasattr(m, "conv1"))
         self.layers = []        # (packed weight, pre, post, residual?, c_in, h_in, pad)
-        self._keep = []
 
         def add(conv, pre, post, res, c_in, h_in, pad):
             wp = pack_conv_weight(conv.weight)
@@ -116,7 +115,6 @@ class FastOthelloNet(torch.nn.Module):
     @torch.no_grad()
     def body(self, x, action_mask):
         """(B, 3, 8, 8) planes + (B, 65) mask -> hidden (B, 10, 10, 256) NHWC bf16"""
-        net = self.net
         s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         mask = action_mask.view(torch.bool) if action_mask.dtype == torch.uint8 else action_mask.to(torch.bool)
         bsz = x.shape[0]

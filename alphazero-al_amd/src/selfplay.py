@@ -26,7 +26,6 @@ reference harness, which carries finished games to the end and samples with nump
 global generator (player.py:348-371).  Not restated: the noise-epsilon decay over the plies
 of a game (game.py:88-92, `noise_steps`; off in the server defaults).
 """
-import ctypes as C
 
 import numpy as np
 import torch

@@ -13,7 +13,6 @@ sys.path[:0] = [os.path.join(ROOT, "alphazero-al_amd"), ROOT]
 
 import torch  # noqa: E402
 from src.az_net import Connect4Net  # noqa: E402
-from src.selfplay import DeviceSelfPlay  # noqa: E402
 
 
 def main():
