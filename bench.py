@@ -95,11 +95,25 @@ def cpu_baseline(args, rank):
     import torch
     ref_dirs = [os.path.join(ROOT, "oracle", "_ref", v) for v in ("portable", "native")]
     ref_dir = next((d for d in ref_dirs if os.path.isdir(os.path.join(d, "src"))), None)
-    if ref_dir is None:
-        return None
+    if os.environ.get("AZ_BENCH_FORCE_PORT") == "1":
+        ref_dir = None
     cores = host_cores()
-    log(f"cpu_baseline: reference C++/OpenMP search + CNN on {cores} host threads ...")
-    code = f"""
+    if ref_dir is None:
+        # oracle/_ref did not travel: the plain-C restatement (oracle/, single-threaded search) takes its place
+        kind, games = "port", min(args.cpu_games, 64)
+        log(f"cpu_baseline: oracle C restatement (1 thread) + CNN on {cores} host threads ...")
+        head = f"""
+import sys, time, json, os
+import numpy as np, torch
+sys.path[:0] = [{PKG!r}, {ROOT!r}]
+from oracle import oracle as O                 # CPU restatement of the reference search (test infrastructure)
+from src import MCTS_cpp as W
+W._BACKENDS['Connect4'] = O.BatchedMCTS_Connect4
+"""
+    else:
+        kind, games = "reference", args.cpu_games
+        log(f"cpu_baseline: reference C++/OpenMP search + CNN on {cores} host threads ...")
+        head = f"""
 import sys, time, json, os
 import numpy as np, torch
 sys.path[:0] = [{ref_dir!r}, {PKG!r}]
@@ -107,11 +121,14 @@ from src import mcts_cpp                       # the REFERENCE's compiled module
 import importlib.util
 spec = importlib.util.spec_from_file_location('az_wrap', os.path.join({PKG!r}, 'src', 'MCTS_cpp.py'))
 W = importlib.util.module_from_spec(spec); spec.loader.exec_module(W)
+"""
+    code = head + f"""
+import importlib.util
 spec = importlib.util.spec_from_file_location('az_net', os.path.join({PKG!r}, 'src', 'az_net.py'))
 N = importlib.util.module_from_spec(spec); spec.loader.exec_module(N)
 torch.manual_seed(0); torch.set_num_threads({cores})
 net = N.Connect4Net(device='cpu').eval()
-B, n, K, plies = {args.cpu_games}, {args.n_playout}, {args.vl_batch}, {args.cpu_plies}
+B, n, K, plies = {games}, {args.n_playout}, {args.vl_batch}, {args.cpu_plies}
 w = W.BatchedMCTS(B, c_init=1.4, c_base=5*n, alpha=0.3, n_playout=n, noise_epsilon=0.25,
                   fpu_reduction=0.2, use_symmetry=True, mlh_slope=0.1, mlh_cap=0.2)
 w.seed(0)
@@ -136,10 +153,11 @@ print(json.dumps(dict(value=B*plies/dt, seconds=dt, positions=B*plies)))
     except Exception as e:                      # the baseline is a reported extra, never fatal
         sys.stderr.write(f"cpu_baseline failed: {e}\n")
         return None
-    return {"value": round(r["value"], 2), "unit": "positions/s", "cores": cores, "kind": "reference",
-            "sample": f"{args.cpu_games} games x {args.cpu_plies} plies, n_playout={args.n_playout}, "
-                      f"vl_batch={args.vl_batch}, reference C++/OpenMP search (oracle/_ref/{os.path.basename(ref_dir)}) "
-                      f"+ same CNN fp32 on CPU, {r['seconds']:.1f} s"}
+    what = (f"reference C++/OpenMP search (oracle/_ref/{os.path.basename(ref_dir)})" if kind == "reference"
+            else "oracle/ C restatement of the reference search, one thread")
+    return {"value": round(r["value"], 2), "unit": "positions/s", "cores": cores, "kind": kind,
+            "sample": f"{games} games x {args.cpu_plies} plies, n_playout={args.n_playout}, "
+                      f"vl_batch={args.vl_batch}, {what} + same CNN fp32 on CPU ({cores} torch threads), {r['seconds']:.1f} s"}
 
 
 def conv_roofline(torch, fast, leaves, launches=20):
