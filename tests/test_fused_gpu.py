@@ -943,3 +943,34 @@ def test_native_search_refuses_misuse_and_reservation_is_sized(env):
     assert L.az_mcts_capacity(sp.h) >= 100 * 7 * 42
     sp = env["SP"].DeviceSelfPlay(env["H"].HashEvaluator("cuda"), 64, n_playout=40, vl_batch=4, reserve_slots=5000)
     assert L.az_mcts_capacity(sp.h) == 5000
+
+
+def test_full_size_native_loop_properties(env):
+    """BASELINE config 1's size through the product path (az_mcts_dev_search with the HIP evaluator,
+    compact batches): 8192 trees x 200 simulations, K = 4, no randomness.  Size-independent
+    properties: every root saw n_playout visits; 128 copies of 64 positions grow 128 identical
+    forests (each leaf is evaluated independently of its batch, whatever rows it shares it with);
+    and the first 64 trees equal a 64-tree engine run on the same positions - a different batch
+    size, the hipGraph loop instead of the native one."""
+    wts = load("g7_checkpoint_weights")
+    net = env["N"].Connect4Net(device="cuda").eval()
+    env["N"].load_reference_weights(net, {k: wts[k] for k in wts.files})
+    B, n, K = 8192, 200, 4
+    rng = np.random.default_rng(17)
+    b64, t64 = S.random_openings(rng, 64, 12)
+    boards = np.tile(b64, (B // 64, 1, 1)); turns = np.tile(t64, B // 64)
+    kw = dict(noise_epsilon=0.0, fpu_reduction=0.2, use_symmetry=False, mlh_slope=0.1)
+    w = env["W"].BatchedMCTS(B, 1.4, 1000, 0.0, n, **kw)
+    w.batch_playout(net, boards, turns, vl_batch=K, fused=True)
+    assert w._fused._native_model() is not None
+    c = w.get_visits_count()
+    st = np.array(w.mcts.get_all_root_stats())
+    assert (st[:, 0] == n).all() and (c.sum(1) == n - 1).all()
+    assert np.array_equal(c.reshape(B // 64, 64, 7), np.broadcast_to(c[:64], (B // 64, 64, 7)))
+    assert np.array_equal(bits(st).reshape(B // 64, 64, -1), np.broadcast_to(bits(st[:64]), (B // 64, 64, st.shape[1])))
+    assert np.allclose(st[:, 3] + st[:, 4] + st[:, 5], 1.0, atol=1e-5)
+    small = env["W"].BatchedMCTS(64, 1.4, 1000, 0.0, n, **kw)
+    small.batch_playout(net, b64, t64, vl_batch=K, fused=True)
+    assert small._fused._native_model() is None                      # 64 trees: graph replay of the Python loop
+    assert np.array_equal(small.get_visits_count(), c[:64])
+    assert np.array_equal(bits(np.array(small.mcts.get_all_root_stats())), bits(st[:64]))
