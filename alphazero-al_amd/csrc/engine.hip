@@ -175,6 +175,7 @@ struct az_mcts {
     DevBuf<uint64_t> tt_keys;
     uint64_t tt_mask = 0;
     int64_t select_launches = 0, backprop_launches = 0;
+    const float *noise_eps_tree = nullptr;     // caller-owned device array (az_mcts_dev_set_noise_epsilons)
     // leaf batch of az_mcts_dev_search: evaluator inputs, outputs, compact row list, activations
     DevBuf<float> ev_feat, ev_probs, ev_wdl, ev_ml;
     DevBuf<uint8_t> ev_mask, ev_scratch;
@@ -251,6 +252,7 @@ struct az_mcts {
         p.vl_count = cfg.vl_count; p.use_symmetry = cfg.use_symmetry ? 1 : 0;
         p.cpuct_tab = tab.p; p.tab_n = kCpuctTab;
         p.seed = dev_seed; p.call_ptr = call_ctr.p;
+        p.noise_eps_tree = noise_eps_tree;
         return p;
     }
 
@@ -797,6 +799,11 @@ int az_mcts_dev_backprop(az_mcts *m, int K, int vl, const float *probs, const fl
         if (timed) m->ev_backprop.end(s);
         ++m->backprop_launches;
     });
+}
+
+int az_mcts_dev_set_noise_epsilons(az_mcts *m, const float *per_tree)
+{
+    return guarded([&] { m->noise_eps_tree = per_tree; });
 }
 
 int az_mcts_dev_live_leaves(az_mcts *m, int K, int32_t *leaf_idx, int64_t *leaf_count, void *stream)

@@ -30,6 +30,9 @@ struct SearchParams {
     // hipGraph draws fresh numbers on every replay.
     uint64_t seed;
     const uint64_t *call_ptr;
+    // per-tree root-noise epsilon (n trees, device memory) replacing `noise_eps` when set: the
+    // self-play driver's noise decay over the plies of a game (game.py:87-91), where games have ages
+    const float *noise_eps_tree;
 };
 
 struct TreeArena {

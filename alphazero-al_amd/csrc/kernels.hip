@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(WAVE) k_select(TreeArena ar, RootState rs, Lea
             if (!stop) {
                 const bool has = sub < E;
                 const bool is_root = cur == root;
-                const float ne = p.noise_eps;
+                const float ne = p.noise_eps_tree != nullptr ? p.noise_eps_tree[t] : p.noise_eps;
                 float noise = 0.0f;
                 if (has) {
                     c = hot[R.child_off + sub];
@@ -363,6 +363,7 @@ __global__ void __launch_bounds__(WAVE) k_select_staggered(TreeArena ar, RootSta
     const int tree = blockIdx.x * tpw + grp;
     const bool live = grp < tpw && tree < ar.B;
     const int t = live ? tree : 0;
+    const float tree_ne = p.noise_eps_tree != nullptr ? p.noise_eps_tree[t] : p.noise_eps;
 
     HotRec *hot = ar.hot + static_cast<size_t>(t) * ar.S;
     const ColdRec *cold = ar.cold + static_cast<size_t>(t) * ar.S;
@@ -408,7 +409,7 @@ __global__ void __launch_bounds__(WAVE) k_select_staggered(TreeArena ar, RootSta
                 noise[j] = 0.0f;
                 if (!stop[j] && sub < E) {
                     c[j] = hot[R[j].child_off + sub];
-                    if (cur[j] == root && p.noise_eps > 0.0f) noise[j] = cold[R[j].child_off + sub].noise;
+                    if (cur[j] == root && tree_ne > 0.0f) noise[j] = cold[R[j].child_off + sub].noise;
                 }
             }
         }
@@ -426,7 +427,7 @@ __global__ void __launch_bounds__(WAVE) k_select_staggered(TreeArena ar, RootSta
             if (!stp) {
                 const bool has = sub < E;
                 const bool is_root = cur[j] == root;
-                const float ne = p.noise_eps;
+                const float ne = tree_ne;
                 const bool exists = has && (cc.meta & META_EXISTS);
                 const bool real = exists && cc.n_visits > 0;
                 const float pq = mean_q(R[j].n_visits, R[j].w_p1, R[j].w_p2, (meta & META_TURN_P1) != 0);

@@ -23,8 +23,8 @@ terminal tuple) - SURVEY section 8f row f1.  Two switches exist for parity tests
 reference harness, which carries finished games to the end and samples with numpy:
 `refill=False` leaves a finished slot dead instead of starting a new game in it, and
 `sampler="reference"` draws the moves on the host with the reference's procedure and numpy's
-global generator (player.py:348-371).  Not restated: the noise-epsilon decay over the plies
-of a game (game.py:88-92, `noise_steps`; off in the server defaults).
+global generator (player.py:348-371).  The noise-epsilon decay over the plies of a game
+(game.py:87-91, `noise_steps`) is per game here (fixture G14 pins the lockstep case).
 """
 
 import numpy as np
@@ -39,7 +39,8 @@ class DeviceSelfPlay:
                  noise_epsilon=0.25, fpu_reduction=0.2, use_symmetry=True, mlh_slope=0.1, mlh_cap=0.2,
                  value_decay=1.0, temperature=1.0, temp_decay_moves=20, temp_endgame=0.0, seed=0,
                  reserve_slots=None, record=False, td_steps=0, refill=True, sampler="device",
-                 max_finished_games=None, table_log2=0, game="Connect4", score_utility_factor=0.0, score_scale=8.0):
+                 max_finished_games=None, table_log2=0, game="Connect4", score_utility_factor=0.0, score_scale=8.0,
+                 noise_steps=0, noise_eps_min=0.1):
         self.B = int(n_games)
         self.n_playout = int(n_playout)
         self.vl_batch = int(vl_batch)
@@ -103,6 +104,14 @@ class DeviceSelfPlay:
         # the host only enqueues; it may run at most `max_plies_ahead` plies ahead of the device
         self.max_plies_ahead = 1
         self._ply_events = []
+        # noise-epsilon decay over the plies of a game (game.py:87-91 with AlphaZeroPlayer.noise_steps /
+        # noise_eps_min, player.py:122,159-161): the reference moves ONE epsilon for a batch of games that
+        # start together; here every game decays from its own first ply (az_mcts_dev_set_noise_epsilons)
+        self.noise_steps, self.noise_eps_init, self.noise_eps_min = int(noise_steps), float(noise_epsilon), float(noise_eps_min)
+        if self.noise_steps > 0:
+            self.eps_tree = torch.full((self.B,), self.noise_eps_init, dtype=torch.float32, **z)
+            F.lib().az_mcts_dev_set_noise_epsilons.argtypes = [F.C.c_void_p, F.C.c_void_p]
+            F.check(F.lib().az_mcts_dev_set_noise_epsilons(self.h, self.eps_tree.data_ptr()))
         if self.record:
             A = self.search.action_size
             self.stats = torch.zeros((self.B, 6 + 8 * A), dtype=torch.float32, **z)
@@ -203,6 +212,10 @@ class DeviceSelfPlay:
         s = F._stream()
         F.check(L.az_mcts_dev_set_roots(self.h, self.bb_p1.data_ptr(), self.bb_p2.data_ptr(),
                                         self.turn.data_ptr(), s))
+        if self.noise_steps > 0:
+            # in double, as the reference's Python arithmetic, then one rounding to the config's float
+            decay = (1.0 - self.ply.double() / self.noise_steps).clamp_min(0.0)
+            self.eps_tree.copy_((self.noise_eps_min + (self.noise_eps_init - self.noise_eps_min) * decay).float())
         self.fused.search(self.n_playout, self.vl_batch)
         F.check(L.az_mcts_dev_counts(self.h, self.counts.data_ptr(), s))
         if self.sampler == "reference":

@@ -175,6 +175,14 @@ int az_game_dev_step(int game, uint64_t *bb_p1, uint64_t *bb_p2, int32_t *turns,
 int az_game_dev_valid_mask(int game, const uint64_t *bb_p1, const uint64_t *bb_p2, const int32_t *turns,
                            const int32_t *aux, uint8_t *mask, int64_t n, void *stream);
 
+/* Root-noise epsilon PER TREE: `per_tree` (n_envs floats in DEVICE memory, owned and kept alive by the
+ * caller; NULL switches back to the config's scalar) replaces az_search_config.noise_epsilon in every
+ * selection from the next launch on.  The reference decays one global epsilon over the plies of a batch
+ * of games that start together (game.py:87-91, AlphaZeroPlayer.noise_steps); a driver that refills
+ * finished slots has games of all ages in one batch and needs the value per game.  The array is read by
+ * the kernels when they run: update it in stream order. */
+int az_mcts_dev_set_noise_epsilons(az_mcts *m, const float *per_tree);
+
 /* The leaves of the last az_mcts_dev_select that an evaluator has to see - all but the terminal
  * ones, as the reference's wrapper evaluates them (MCTS_cpp.py:275-297): their flat indices go to
  * leaf_idx[0 .. *leaf_count) (int32 [n*K] and int64 [1] in DEVICE memory; order unspecified). */

@@ -286,6 +286,29 @@ def gen_g10():
     save("g10_selfplay_numpy_rng", **out)
 
 
+def gen_g14():
+    """G10's harness with the noise-epsilon decay on (AlphaZeroPlayer.noise_steps, game.py:87-91): the
+    epsilon that scales the root priors falls from 0.25 to 0.05 over the first 6 plies.  alpha = 0, so
+    no Dirichlet draw is consumed and every random number is numpy's."""
+    from src.game import Game
+    from src.player import AlphaZeroPlayer
+    pv = S.HashPV()
+    np.random.seed(29)
+    player = AlphaZeroPlayer(pv, n_envs=12, c_init=1.4, c_base=240, n_playout=48, alpha=0.0,
+                             is_selfplay=1, noise_epsilon=0.25, fpu_reduction=0.2,
+                             use_symmetry=False, mlh_slope=0.1, mlh_cap=0.2, vl_batch=4,
+                             noise_steps=6, noise_eps_min=0.05)
+    player.mcts.seed(3)
+    data = Game(Env()).batch_self_play(player, 12, temperature=1.0, temp_decay_moves=8, temp_endgame=0,
+                                       td_steps=2)
+    out = {}
+    for i, (winner, play) in enumerate(data):
+        out[f"g{i}_winner"] = np.array([winner], np.int32)
+        for j, nm in enumerate(("state", "prob", "z", "steps", "aux", "root_wdl", "mask", "fut")):
+            out[f"g{i}_{nm}"] = np.array([np.asarray(tup[j]) for tup in play])
+    save("g14_selfplay_noise_decay", **out)
+
+
 # ------------------------------------------------------------------ G11: the harness without virtual loss and without td targets
 def gen_g11():
     """As G10 with the other branches of the harness: vl_batch=1 (the plain search loop,
@@ -433,8 +456,8 @@ def gen_othello():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rng", "g1", "g2", "search", "g6", "rollout", "g7", "g8", "g10", "g11", "g12", "g13", "gomoku", "othello"]
+    which = sys.argv[1:] or ["rng", "g1", "g2", "search", "g6", "rollout", "g7", "g8", "g10", "g11", "g12", "g13", "g14", "gomoku", "othello"]
     fns = dict(rng=gen_rng, g1=gen_g1, g2=gen_g2, search=gen_search, g6=gen_g6,
-               rollout=gen_rollout, g7=gen_g7, g8=gen_g8, g10=gen_g10, g11=gen_g11, g12=gen_g12, g13=gen_g13, gomoku=gen_gomoku, othello=gen_othello)
+               rollout=gen_rollout, g7=gen_g7, g8=gen_g8, g10=gen_g10, g11=gen_g11, g12=gen_g12, g13=gen_g13, g14=gen_g14, gomoku=gen_gomoku, othello=gen_othello)
     for w in which:
         fns[w]()

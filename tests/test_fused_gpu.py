@@ -647,6 +647,59 @@ def test_device_selfplay_trajectories_equal_reference_harness_g10(env):
             assert len(ta) == len(tb) and all(type(x) is type(y) and np.array_equal(x, y) for x, y in zip(ta, tb))
 
 
+def test_device_selfplay_noise_epsilon_decay_g14(env):
+    """Fixture G14: the reference harness with AlphaZeroPlayer.noise_steps = 6 (the epsilon that scales
+    the root priors decays from 0.25 to 0.05 over the first plies, game.py:87-91).  The driver keeps
+    one epsilon per game (az_mcts_dev_set_noise_epsilons); with all games started together that is the
+    reference's single value, and the play data must match bit for bit."""
+    g = load("g14_selfplay_noise_decay")
+    net = env["H"].HashEvaluator("cuda")
+    np.random.seed(29)
+    sp = env["SP"].DeviceSelfPlay(net, 12, n_playout=48, vl_batch=4, c_init=1.4, c_base=240, alpha=0.0,
+                                  noise_epsilon=0.25, fpu_reduction=0.2, use_symmetry=False, mlh_slope=0.1,
+                                  mlh_cap=0.2, temperature=1.0, temp_decay_moves=8, temp_endgame=0, seed=3,
+                                  record=True, td_steps=2, refill=False, sampler="reference",
+                                  noise_steps=6, noise_eps_min=0.05)
+    for _ in range(43):
+        sp.step()
+        if bool(sp.dead.all()):
+            break
+    assert bool(sp.dead.all())
+    games = sorted(sp.drain(), key=lambda t: t[2])
+    assert [t[2] for t in games] == list(range(12))
+    for i, (winner, play, _slot) in enumerate(games):
+        assert winner == int(g[f"g{i}_winner"][0]), i
+        for j, nm in enumerate(("state", "prob", "z", "steps", "aux", "root_wdl", "mask", "fut")):
+            got = np.array([np.asarray(t[j]) for t in play])
+            ref = g[f"g{i}_{nm}"]
+            assert got.shape == ref.shape and got.dtype == ref.dtype, (i, nm)
+            if ref.dtype.kind == "f":
+                assert np.array_equal(bits(got), bits(ref)), (i, nm)
+            else:
+                assert np.array_equal(got, ref), (i, nm)
+    # the decay is observable: without it the same seeds give other games
+    np.random.seed(29)
+    flat = env["SP"].DeviceSelfPlay(net, 12, n_playout=48, vl_batch=4, c_init=1.4, c_base=240, alpha=0.0,
+                                    noise_epsilon=0.25, fpu_reduction=0.2, use_symmetry=False, mlh_slope=0.1,
+                                    mlh_cap=0.2, temperature=1.0, temp_decay_moves=8, temp_endgame=0, seed=3,
+                                    record=True, td_steps=2, refill=False, sampler="reference")
+    for _ in range(43):
+        flat.step()
+        if bool(flat.dead.all()):
+            break
+    other = sorted(flat.drain(), key=lambda t: t[2])
+    assert any(len(a[1]) != len(b[1]) or not all(np.array_equal(x[1], y[1]) for x, y in zip(a[1], b[1]))
+               for a, b in zip(games, other))
+    # refill mode: every game decays from its own first ply
+    sp2 = env["SP"].DeviceSelfPlay(net, 64, n_playout=24, vl_batch=4, seed=1, noise_steps=5, noise_eps_min=0.05)
+    for _ in range(30):
+        sp2.step()
+    want = 0.05 + (0.25 - 0.05) * np.maximum(0.0, 1.0 - (sp2.ply.cpu().numpy() - 1) / 5)      # set before the ply counter moved
+    got = sp2.eps_tree.cpu().numpy()
+    fresh = sp2.ply.cpu().numpy() == 0                               # slots refilled this ply still show the old game's value
+    assert np.allclose(got[~fresh], want[~fresh].astype(np.float32), atol=1e-7) and len(set(np.round(got, 4))) > 2
+
+
 def test_device_selfplay_trajectories_plain_search_g11(env):
     """Fixture G11: the same harness on its other branches - no virtual loss (vl_batch 1), no
     td-step targets (7-tuples), every move sampled (no temperature switch), value decay 0.98,
