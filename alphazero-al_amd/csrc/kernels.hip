@@ -165,6 +165,7 @@ __global__ void __launch_bounds__(WAVE) k_select(TreeArena ar, RootState rs, Lea
     const int tree = blockIdx.x * tpw + grp;
     const bool live = grp < tpw && tree < ar.B;
     const int t = live ? tree : 0;
+    const float tree_ne = p.noise_eps_tree != nullptr ? p.noise_eps_tree[t] : p.noise_eps;   // root-noise epsilon of this tree
 
     HotRec *hot = ar.hot + static_cast<size_t>(t) * ar.S;
     const ColdRec *cold = ar.cold + static_cast<size_t>(t) * ar.S;
@@ -196,7 +197,7 @@ __global__ void __launch_bounds__(WAVE) k_select(TreeArena ar, RootState rs, Lea
             if (!stop) {
                 const bool has = sub < E;
                 const bool is_root = cur == root;
-                const float ne = p.noise_eps_tree != nullptr ? p.noise_eps_tree[t] : p.noise_eps;
+                const float ne = tree_ne;
                 float noise = 0.0f;
                 if (has) {
                     c = hot[R.child_off + sub];
