@@ -596,6 +596,15 @@ def test_streamed_selfplay_equals_its_drivers_run_alone(env):
             for a, b in zip(play0, play1):
                 assert all(np.array_equal(x, y) for x, y in zip(a, b))
     sp.close()
+    # with the device transposition table: per-driver tables, aggregated statistics, same games
+    spt = env["SP"].StreamedSelfPlay(net, 1300, streams=2, seed=3, table_log2=14, **kw)
+    spt.step(plies)
+    st = spt.table_stats()
+    assert st["hits"] > 0 and st["lookups"] >= st["hits"] + st["inserts"] - 2 and 0.0 < st["hit_rate"] < 1.0
+    assert spt.read_totals() == tot
+    for a, b in zip(sp.parts, spt.parts):
+        assert torch.equal(a.bb_p1, b.bb_p1) and torch.equal(a.bb_p2, b.bb_p2)
+    spt.close()
 
 
 def test_device_selfplay_trajectories_equal_reference_harness_g10(env):
