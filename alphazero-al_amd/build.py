@@ -31,21 +31,41 @@ def _stale(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
+def _headers():
+    """Every header a native piece may include: editing one (the game rules in games.h, the record
+    layout, the C ABI) rebuilds the engine AND the modules."""
+    import glob
+    return sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INC, "*.h")))
+
+
 def _run(cmd):
     print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
 
 
 def build_engine(force=False):
+    """One object per .hip source (compiled in parallel, rebuilt only when that source or a header
+    changed), linked into lib/libaz_mcts.so.  No device code crosses translation units."""
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIB, exist_ok=True)
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
     out = os.path.join(LIB, "libaz_mcts.so")
-    srcs = [os.path.join(CSRC, f) for f in ("kernels.hip", "tt_kernels.hip", "engine.hip", "nn_kernels.hip", "nn_conv.hip", "nn_attn.hip", "nn_heads.hip", "nn_model.hip", "nn_othello.hip")]
-    deps = srcs + [os.path.join(CSRC, f) for f in ("kernels.h", "tree_layout.h", "host_rng.h")] + \
-        [os.path.join(INC, "az_mcts.h"), os.path.join(INC, "az_nn.h")]
-    if force or _stale(out, deps):
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        _run([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
-              "-shared", "-I", INC, "-I", CSRC, *srcs, "-o", out])
+    names = ("kernels", "tt_kernels", "engine", "nn_kernels", "nn_conv", "nn_attn", "nn_heads", "nn_model", "nn_othello")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    headers = _headers()
+    jobs = []
+    for n in names:
+        src, obj = os.path.join(CSRC, n + ".hip"), os.path.join(objdir, n + ".o")
+        if force or _stale(obj, [src] + headers):
+            jobs.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+                         "-I", INC, "-I", CSRC, "-c", src, "-o", obj])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as pool:
+            list(pool.map(_run, jobs))
+    objs = [os.path.join(objdir, n + ".o") for n in names]
+    if force or jobs or _stale(out, objs):
+        _run([hipcc, f"--offload-arch={ARCH}", "-fPIC", "-shared", *objs, "-o", out])
     return out
 
 
@@ -54,7 +74,7 @@ def build_module(name, source, link_engine, force=False):
     os.makedirs(SRC, exist_ok=True)
     out = os.path.join(SRC, name + EXT)
     src = os.path.join(CSRC, source)
-    if force or _stale(out, [src, os.path.join(INC, "az_mcts.h")]):
+    if force or _stale(out, [src] + _headers()):
         cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden",
                "-I", INC, "-I", pybind11.get_include(), "-I", sysconfig.get_paths()["include"],
                src, "-o", out]

@@ -168,7 +168,12 @@ struct az_mcts {
 
     DevBuf<unsigned long long> counters;
     DevBuf<int> err;
+    int *err_host = nullptr;  // pinned copy of `err` (az_mcts_dev_check)
     DevBuf<uint64_t> call_ctr;
+    // recorded draws that stand in for the device generator (az_mcts_dev_replay; parity tests)
+    const int32_t *replay_sym = nullptr;
+    int64_t replay_stride = 0, replay_calls = 0, replay_next = 0;
+    const float *replay_noise = nullptr;
     // device transposition table of evaluator outputs (tt_kernels.hip)
     DevBuf<az::TtEntry> tt_entries;
     DevBuf<unsigned long long> tt_stats;
@@ -259,6 +264,7 @@ struct az_mcts {
     void flush_resets(hipStream_t s)
     {
         if (!any_pending_reset) return;
+        HIP_OK(hipStreamSynchronize(s));          // an earlier reset launch may still be reading the mask
         io_reset_mask.ensure(B);
         HIP_OK(hipMemcpy(io_reset_mask.p, pending_reset.data(), B, hipMemcpyHostToDevice));
         az::launch_reset_masked(arena(), io_reset_mask.p, s);
@@ -307,9 +313,19 @@ struct az_mcts {
         HIP_OK(hipMemcpy(&e, err.p, sizeof(int), hipMemcpyDeviceToHost));
         if (e) {
             HIP_OK(hipMemset(err.p, 0, sizeof(int)));
-            throw AzError(AZ_ERR_CAPACITY, "tree arena overflow on device");
+            if (err_host) *err_host = 0;
+            throw AzError(AZ_ERR_CAPACITY, device_error_text(e));
         }
     }
+    static std::string device_error_text(int e)
+    {
+        std::string msg;
+        if (e & az::ERR_ARENA_OVERFLOW) msg += "tree arena overflow on device (expansions were dropped)";
+        if (e & az::ERR_LIST_OVERFLOW) msg += std::string(msg.empty() ? "" : "; ") + "compact leaf list overflow on device (entries were dropped)";
+        if (msg.empty()) msg = "device error word " + std::to_string(e);
+        return msg;
+    }
+    ~az_mcts() { if (err_host) (void)hipHostFree(err_host); }
 };
 
 namespace {
@@ -343,6 +359,8 @@ az_mcts *create_engine(int game, int n_envs, int device)
         m->r_turn.ensure(n_envs, true); m->r_last.ensure(n_envs, true);
         m->counters.ensure(az::CNT_N * az::CNT_STRIPES, true);
         m->err.ensure(1, true);
+        HIP_OK(hipHostMalloc(reinterpret_cast<void **>(&m->err_host), sizeof(int), hipHostMallocDefault));
+        *m->err_host = 0;
         m->call_ctr.ensure(1, true);
         m->plain_leaf.ensure(n_envs);
         m->pending_reset.assign(n_envs, 0);
@@ -727,17 +745,64 @@ int az_mcts_get_all_root_stats(az_mcts *m, float *out)
 
 // ---------------------------------------------------------------- device entry points
 
+namespace {
+// stream == nullptr with whole_device: everything on the device is waited for (callers that do not
+// say which stream their trees are being worked on)
+void dev_prepare(az_mcts *m, int K, int64_t sims_per_tree, hipStream_t s, bool whole_device)
+{
+    require(K >= 1, "dev_prepare: K must be >= 1");
+    HIP_OK(hipSetDevice(m->device));
+    const size_t total = static_cast<size_t>(m->B) * K;
+    const int64_t extra = sims_per_tree * m->geo.actions;
+    // Reading the trees' fill (`used`), moving the arenas or the leaf buffers, refreshing the tables:
+    // all of that must see what the kernels already enqueued have done, and must not pull memory
+    // from under them.  Wait for them first - once per many calls (the host-side bound `used_bound`
+    // runs ahead of the real fill by at most one call's worth).
+    const bool touches = m->any_pending_reset || total > m->vl_leaf.slot.n || static_cast<size_t>(m->B) > m->plain_leaf.slot.n ||
+                         !m->tab.p || !m->term_tab.p || m->cfg.c_init != m->tab_c_init || m->cfg.c_base != m->tab_c_base ||
+                         m->cfg.score_scale != m->term_tab_scale || m->used_bound + extra > m->S;
+    if (touches) {
+        if (whole_device) HIP_OK(hipDeviceSynchronize());
+        else HIP_OK(hipStreamSynchronize(s));
+    }
+    m->flush_resets(s);
+    if (total > m->vl_leaf.slot.n) ++m->epoch;
+    m->vl_leaf.ensure(total);
+    m->plain_leaf.ensure(m->B);
+    m->ensure_table();
+    m->ensure_room(extra);
+}
+}  // namespace
+
 int az_mcts_dev_prepare(az_mcts *m, int K, int64_t sims_per_tree)
 {
+    return guarded([&] { dev_prepare(m, K, sims_per_tree, nullptr, true); });
+}
+
+int az_mcts_dev_prepare_stream(az_mcts *m, int K, int64_t sims_per_tree, void *stream)
+{
+    return guarded([&] { dev_prepare(m, K, sims_per_tree, static_cast<hipStream_t>(stream), false); });
+}
+
+int az_mcts_dev_check(az_mcts *m, void *stream)
+{
     return guarded([&] {
-        require(K >= 1, "dev_prepare: K must be >= 1");
-        HIP_OK(hipSetDevice(m->device));
-        m->flush_resets(nullptr);
-        if (static_cast<size_t>(m->B) * K > m->vl_leaf.slot.n) ++m->epoch;
-        m->vl_leaf.ensure(static_cast<size_t>(m->B) * K);
-        m->plain_leaf.ensure(m->B);
-        m->ensure_table();
-        m->ensure_room(sims_per_tree * m->geo.actions);
+        const int seen = *static_cast<volatile int *>(m->err_host);
+        HIP_OK(hipMemcpyAsync(m->err_host, m->err.p, sizeof(int), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+        if (seen) throw AzError(AZ_ERR_CAPACITY, az_mcts::device_error_text(seen));
+    });
+}
+
+int az_mcts_dev_replay(az_mcts *m, const int32_t *sym_ids, int64_t sym_stride, int64_t n_select_calls,
+                       const float *root_noise)
+{
+    return guarded([&] {
+        require(sym_ids == nullptr || (sym_stride > 0 && n_select_calls > 0), "dev_replay: a symmetry tape needs a stride and a length");
+        m->replay_sym = sym_ids;
+        m->replay_stride = sym_ids ? sym_stride : 0;
+        m->replay_calls = sym_ids ? n_select_calls : 0;
+        m->replay_next = 0;
+        m->replay_noise = root_noise;
     });
 }
 
@@ -772,7 +837,19 @@ void select_and_gather(az_mcts *m, int K, int vl, float *features, uint8_t *vali
     const bool timed = m->profiling && (m->profile_seen[0]++ % m->profile_stride) == 0 && m->ev_select.begin(s);
     az::launch_select(m->game, m->arena(), m->roots(), ls.view(), p, K, vl != 0, m->counters.p, s, m->call_ctr.p, zero_count);
     if (timed) m->ev_select.end(s);
-    az::launch_export(m->game, ls.view(), p, static_cast<int>(total), true, nullptr, valid_mask, features, s);
+    bool gen_sym = true;
+    if (m->replay_sym != nullptr) {             // recorded symmetry ids instead of the generator's
+        if (m->replay_next >= m->replay_calls || static_cast<int64_t>(total) > m->replay_stride)
+            throw AzError(AZ_ERR_STATE, "dev_select: the replay tape (az_mcts_dev_replay) is exhausted or too narrow");
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            throw AzError(AZ_ERR_STATE, "dev_select: a replay tape cannot be captured into a graph (its position moves per call)");
+        HIP_OK(hipMemcpyAsync(ls.sym.p, m->replay_sym + m->replay_next * m->replay_stride, sizeof(int32_t) * total,
+                              hipMemcpyDeviceToDevice, s));
+        ++m->replay_next;
+        gen_sym = false;
+    }
+    az::launch_export(m->game, ls.view(), p, static_cast<int>(total), gen_sym, nullptr, valid_mask, features, s);
     ++m->select_launches;
 }
 }  // namespace
@@ -791,7 +868,7 @@ int az_mcts_dev_backprop(az_mcts *m, int K, int vl, const float *probs, const fl
         LeafStore &ls = vl ? m->vl_leaf : m->plain_leaf;
         az::EvalIn in{};
         in.policy = probs; in.wdl_rel = wdl_rel; in.moves_left = moves_left;
-        in.root_noise = nullptr; in.sym = nullptr;
+        in.root_noise = m->replay_noise; in.sym = nullptr;
         hipStream_t s = static_cast<hipStream_t>(stream);
         const bool timed = m->profiling && (m->profile_seen[1]++ % m->profile_stride) == 0 && m->ev_backprop.begin(s);
         az::launch_backprop(m->game, m->arena(), ls.view(), m->params(), K, vl != 0, true, in, m->counters.p,
@@ -812,7 +889,7 @@ int az_mcts_dev_live_leaves(az_mcts *m, int K, int32_t *leaf_idx, int64_t *leaf_
         LeafStore &ls = m->last_select_vl ? m->vl_leaf : m->plain_leaf;
         const size_t total = static_cast<size_t>(m->B) * K;
         require(K >= 1 && ls.slot.n >= total, "dev_live_leaves: no selection of that width");
-        az::launch_live_leaves(ls.view(), static_cast<int>(total), leaf_idx, leaf_count, static_cast<hipStream_t>(stream));
+        az::launch_live_leaves(ls.view(), static_cast<int>(total), leaf_idx, leaf_count, m->err.p, static_cast<hipStream_t>(stream));
     });
 }
 
@@ -824,7 +901,10 @@ int az_mcts_dev_search(az_mcts *m, const az_nn_model *model, int n_playout, int 
 {
     return guarded([&] {
         require(model != nullptr, "dev_search: no evaluator model");
-        require(m->game == AZ_GAME_CONNECT4, "dev_search: the native evaluator is the Connect4 network");
+        const int kind = az_nn_model_kind(model);
+        require(kind == (m->game == AZ_GAME_CONNECT4 ? AZ_NN_KIND_HASH_CONNECT4 : AZ_NN_KIND_HASH_OTHELLO) ||
+                    (kind == AZ_NN_KIND_CONNECT4_CNN && m->game == AZ_GAME_CONNECT4),
+                "dev_search: the evaluator model does not belong to this engine's game");
         require(K >= 1 && n_playout >= 0, "dev_search: K must be >= 1 and n_playout >= 0");
         require(!use_table || m->tt_entries.p != nullptr, "dev_search: no table (az_mcts_dev_tt_create)");
         hipStream_t s = static_cast<hipStream_t>(stream);
@@ -836,7 +916,7 @@ int az_mcts_dev_search(az_mcts *m, const az_nn_model *model, int n_playout, int 
                            m->used_bound + extra > m->S || (use_table && m->tt_keys.n < 2 * total);
         // anything below that allocates, frees or reads a buffer the stream's kernels use waits for them first
         if (grows) HIP_OK(hipStreamSynchronize(s));
-        if (az_mcts_dev_prepare(m, K, n_playout) != AZ_OK) throw AzError(AZ_ERR_DEVICE, g_last_error);
+        dev_prepare(m, K, n_playout, s, false);
         if (total > m->ev_rows.n) {
             m->ev_feat.ensure(total * 3 * m->geo.cells); m->ev_mask.ensure(total * m->geo.actions);
             m->ev_probs.ensure(total * m->geo.actions); m->ev_wdl.ensure(total * 3); m->ev_ml.ensure(total);
@@ -854,8 +934,8 @@ int az_mcts_dev_search(az_mcts *m, const az_nn_model *model, int n_playout, int 
             if (use_table)
                 ok(az_mcts_dev_tt_lookup(m, k, m->ev_probs.p, m->ev_wdl.p, m->ev_ml.p, m->ev_rows.p, m->ev_nrows.p, stream), "tt_lookup");
             else
-                az::launch_live_leaves((vl ? m->vl_leaf : m->plain_leaf).view(), static_cast<int>(n), m->ev_rows.p, m->ev_nrows.p, s,
-                                       false);          // the selection launch cleared the count
+                az::launch_live_leaves((vl ? m->vl_leaf : m->plain_leaf).view(), static_cast<int>(n), m->ev_rows.p, m->ev_nrows.p,
+                                       m->err.p, s, false);   // the selection launch cleared the count
             if (az_nn_model_forward(model, m->ev_feat.p, m->ev_mask.p, m->ev_probs.p, m->ev_wdl.p, m->ev_ml.p, n,
                                     m->ev_rows.p, m->ev_nrows.p, m->ev_scratch.p, m->ev_scratch.n, stream) != 0)
                 throw AzError(AZ_ERR_ARG, "dev_search: az_nn_model_forward refused its arguments");
@@ -921,7 +1001,7 @@ int az_mcts_dev_tt_lookup(az_mcts *m, int K, float *probs, float *wdl_rel, float
         }
         az::TtTable t{m->tt_entries.p, m->tt_mask, m->tt_stats.p};
         az::launch_tt_lookup(ls.view(), static_cast<int>(total), t, m->call_ctr.p, probs, wdl_rel, moves_left, miss_idx,
-                             miss_count, m->tt_keys.p, static_cast<hipStream_t>(stream));
+                             miss_count, m->tt_keys.p, m->err.p, static_cast<hipStream_t>(stream));
     });
 }
 
@@ -979,7 +1059,7 @@ int az_mcts_dev_prune_roots(az_mcts *m, const int32_t *actions, void *stream)
 {
     return guarded([&] {
         hipStream_t s = static_cast<hipStream_t>(stream);
-        az::launch_prune(m->game, m->arena(), m->params(), actions, nullptr, true, s);
+        az::launch_prune(m->game, m->arena(), m->params(), actions, nullptr, true, s, m->replay_noise);
         az::launch_bump_call(m->call_ctr.p, s);
     });
 }

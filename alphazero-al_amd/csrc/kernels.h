@@ -94,6 +94,10 @@ struct TtTable {
     unsigned long long *stats;                      // lookups, hits, inserts, replaced
 };
 
+// bits of the engine's sticky device error word
+constexpr int ERR_ARENA_OVERFLOW = 1;   // an expansion found no room in its tree's arena (it was dropped)
+constexpr int ERR_LIST_OVERFLOW  = 2;   // a compact leaf list was asked to hold more entries than leaves exist
+
 enum : int { CNT_SIMS = 0, CNT_LEVELS, CNT_EXPANSIONS, CNT_TERMINAL, CNT_DUP, CNT_BACKUP,
              CNT_SELECT_LAUNCHES, CNT_BACKPROP_LAUNCHES, CNT_N };
 constexpr int CNT_STRIPES = 64;      // striped copies of the counters (CNT_N * 8 B = one 64-byte line each)
@@ -115,8 +119,10 @@ void launch_remove_vl(int game, TreeArena ar, LeafBuf lf, SearchParams p, int K,
 // LeafBuf::sym).  Any output pointer may be nullptr.
 void launch_export(int game, LeafBuf lf, SearchParams p, int n_leaves, bool gen_sym, int8_t *boards,
                    uint8_t *valid_mask, float *features, hipStream_t s);
+// dev_noise: fresh root noise is written by the launch itself - from the device generator, or from
+// `replay_noise` ([B, A] by edge index) when that is given
 void launch_prune(int game, TreeArena ar, SearchParams p, const int32_t *actions, int32_t *noise_req,
-                  bool dev_noise, hipStream_t s);
+                  bool dev_noise, hipStream_t s, const float *replay_noise = nullptr);
 void launch_apply_noise(int game, TreeArena ar, const int32_t *noise_req, const float *noise, hipStream_t s);
 void launch_reset_masked(TreeArena ar, const uint8_t *mask, hipStream_t s);
 void launch_counts(int game, TreeArena ar, int32_t *counts, hipStream_t s);
@@ -129,9 +135,10 @@ void launch_game_step(int game, uint64_t *bb0, uint64_t *bb1, int32_t *turns, in
 void launch_game_valid_mask(int game, const uint64_t *bb0, const uint64_t *bb1, const int32_t *turns, const int32_t *aux,
                             uint8_t *mask, int64_t n, hipStream_t s);
 
-void launch_live_leaves(LeafBuf lf, int n_leaves, int32_t *idx, int64_t *count, hipStream_t s, bool clear_count = true);
+// err: the engine's sticky error word (ERR_* bits)
+void launch_live_leaves(LeafBuf lf, int n_leaves, int32_t *idx, int64_t *count, int *err, hipStream_t s, bool clear_count = true);
 void launch_tt_lookup(LeafBuf lf, int n_leaves, TtTable t, const uint64_t *clock, float *probs, float *wdl, float *ml,
-                      int32_t *miss_idx, int64_t *miss_count, uint64_t *keys, hipStream_t s);
+                      int32_t *miss_idx, int64_t *miss_count, uint64_t *keys, int *err, hipStream_t s);
 void launch_tt_insert(int n_leaves, TtTable t, const uint64_t *clock, const int32_t *miss_idx, const int64_t *miss_count,
                       const uint64_t *keys, const float *probs, const float *wdl, const float *ml, hipStream_t s);
 

@@ -659,7 +659,7 @@ __global__ void __launch_bounds__(WAVE) k_backprop(TreeArena ar, LeafBuf lf, Sea
                     }
                     const float prior = my_pol / (psum + 1e-8f);    // MCTS.h:370
                     if (static_cast<int64_t>(used) + nv > ar.S) {
-                        if (sub == 0) atomicExch(err, 1);
+                        if (sub == 0) atomicOr(err, ERR_ARENA_OVERFLOW);
                     } else {
                         const bool root_leaf = (len == 1);          // leaf.parent == -1, MCTS.h:349
                         float noise = 0.0f;
@@ -869,7 +869,7 @@ __global__ void __launch_bounds__(WAVE) k_backprop_batched(TreeArena ar, LeafBuf
                     }
                     const float prior = my_pol[k] / (psum + 1e-8f);  // MCTS.h:370
                     if (static_cast<int64_t>(used) + nv[k] > ar.S) {
-                        if (sub == 0) atomicExch(err, 1);
+                        if (sub == 0) atomicOr(err, ERR_ARENA_OVERFLOW);
                     } else {
                         const bool root_leaf = (len[k] == 1);       // leaf.parent == -1, MCTS.h:349
                         float noise = 0.0f;
@@ -1047,7 +1047,7 @@ __device__ __forceinline__ unsigned long long group_ballot(bool pred, int lane)
 // noise (0 if none) for the host generator; with dev_noise the noise is drawn here.
 template <class G>
 __global__ void __launch_bounds__(WAVE) k_prune(TreeArena ar, SearchParams p, const int32_t *actions,
-                                                int32_t *noise_req, int dev_noise)
+                                                int32_t *noise_req, int dev_noise, const float *replay_noise)
 {
     constexpr int L = G::LANES;
     const int lane = threadIdx.x;
@@ -1079,6 +1079,9 @@ __global__ void __launch_bounds__(WAVE) k_prune(TreeArena ar, SearchParams p, co
         const int want = (p.alpha > 0.0f) ? nE : 0;                  // apply_root_noise
         if (!dev_noise) {
             if (sub == 0) noise_req[t] = want;
+        } else if (want > 0 && replay_noise != nullptr) {
+            // recorded draws instead of the generator (az_mcts_dev_replay): row t, edge order
+            if (sub < want) cold[noff + sub].noise = replay_noise[static_cast<size_t>(t) * G::ACTIONS + sub];
         } else if (want > 0) {
             float g = 0.0f;
             if (sub < want) {
@@ -1388,10 +1391,10 @@ void launch_export(int game, LeafBuf lf, SearchParams p, int n_leaves, bool gen_
 }
 
 void launch_prune(int game, TreeArena ar, SearchParams p, const int32_t *actions, int32_t *noise_req,
-                  bool dev_noise, hipStream_t s)
+                  bool dev_noise, hipStream_t s, const float *replay_noise)
 {
     AZ_DISPATCH(game, hipLaunchKernelGGL(k_prune<G>, dim3(grid_for(ar.B, WAVE / G::LANES)), dim3(WAVE), 0, s, ar, p,
-                                         actions, noise_req, dev_noise ? 1 : 0));
+                                         actions, noise_req, dev_noise ? 1 : 0, replay_noise));
 }
 
 void launch_apply_noise(int game, TreeArena ar, const int32_t *noise_req, const float *noise, hipStream_t s)

@@ -122,6 +122,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_block(const uint16_t *x, const 
                                                        int64_t B, float eps, int dbg, const int64_t *batch_dev, EmbedIn em)
 {
     static_assert(!EMBED || (CIN == 32 && !NORM && !RESID), "the embedding is fused into the stem only");
+    const int64_t rows_total = B;                                     // rows of the feature tensor a gather index may name
     if (batch_dev != nullptr && *batch_dev < B) B = *batch_dev;       // compact batch whose size only the device knows
     constexpr int K = 9 * CIN;
     constexpr int KSTEPS = K / 32;                // 18 (C_in 64) or 9 (C_in 32)
@@ -211,7 +212,8 @@ __global__ void __launch_bounds__(256, 2) k_conv_block(const uint16_t *x, const 
     auto load_planes = [&](int64_t tile, int lane) {
         const int64_t b = tile * TS + wave;
         const bool live = b < B;
-        const int64_t row = !live ? 0 : (em.gather != nullptr ? em.gather[b] : b);
+        int64_t row = !live ? 0 : (em.gather != nullptr ? em.gather[b] : b);
+        if (row < 0 || row >= rows_total) row = 0;                    // never dereference an index outside the rows
         const float *fs = em.features + row * (3 * CELLS);
 #pragma unroll
         for (int i = 0; i < PER; ++i) {

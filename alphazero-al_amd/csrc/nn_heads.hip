@@ -144,6 +144,7 @@ __global__ void __launch_bounds__(64 * WPB) k_heads(const uint16_t *tok, az_nn_h
                                                     float *probs, float *wdl, float *moves_left, int64_t B, float eps,
                                                     const int32_t *scatter, const int64_t *batch_dev)
 {
+    const int64_t rows_total = B;                 // rows of mask / outputs: a compact list may name any of them
     if (batch_dev != nullptr && *batch_dev < B) B = *batch_dev;
     extern __shared__ __align__(16) uint8_t smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -309,9 +310,10 @@ __global__ void __launch_bounds__(64 * WPB) k_heads(const uint16_t *tok, az_nn_h
 
         // ======== both samples of the pair: columns 0-6 | 7 and 8-14 | 15 of the B operand ========
         const int64_t bc = 2 * pr + half;             // the sample this lane's column belongs to
-        const bool real = bc < B;
-        // compact batch: sample bc stands for row scatter[bc] of the mask and of the outputs
-        const int64_t b = (real && scatter != nullptr) ? scatter[bc] : bc;
+        // compact batch: sample bc stands for row scatter[bc] of the mask and of the outputs; an index
+        // outside the rows (a list longer than what was written) is dropped, never dereferenced
+        const int64_t b = (bc < B && scatter != nullptr) ? scatter[bc] : bc;
+        const bool real = bc < B && b >= 0 && b < rows_total;
         const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
         f32x4 ap[4], ad[4];
         {

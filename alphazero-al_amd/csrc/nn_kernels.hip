@@ -57,6 +57,7 @@ __global__ void __launch_bounds__(256) k_embed(const float *feat, const uint16_t
                                                const int32_t *gather, const int64_t *batch_dev)
 {
     constexpr int VPT = E / 8;
+    const int64_t rows_total = B;
     if (batch_dev != nullptr && *batch_dev < B) B = *batch_dev;
     const int64_t gid = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const int64_t tok = gid / VPT;
@@ -64,7 +65,8 @@ __global__ void __launch_bounds__(256) k_embed(const float *feat, const uint16_t
     if (tok >= B * CELLS) return;
     const int64_t b = tok / CELLS;
     const int cell = static_cast<int>(tok - b * CELLS);
-    const int64_t src = gather != nullptr ? gather[b] : b;       // row of `feat` that sample b of the compact batch shows
+    int64_t src = gather != nullptr ? gather[b] : b;             // row of `feat` that sample b of the compact batch shows
+    if (src < 0 || src >= rows_total) src = 0;
     const float own = feat[src * 3 * CELLS + cell], opp = feat[src * 3 * CELLS + CELLS + cell];
     float p[8], a[8], o[8], r[8];
     unpack8(*reinterpret_cast<const V8 *>(pos + cell * E + vec * 8), p);

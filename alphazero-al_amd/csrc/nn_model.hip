@@ -15,7 +15,8 @@
 #include "az_nn.h"
 
 struct az_nn_model {
-    az_nn_model_weights w;
+    int kind = AZ_NN_KIND_CONNECT4_CNN;
+    az_nn_model_weights w{};
 };
 
 namespace {
@@ -32,6 +33,84 @@ struct Profile {
     size_t used = 0;
 } g_prof;
 constexpr size_t kProfileMax = 4096;
+
+// ---- integer-hash evaluator (AZ_NN_KIND_HASH_*): not a model, a pure function of the position the
+// feature planes show, built from 64-bit mixing, small integers and one correctly rounded division,
+// so that numpy (tests/scenarios.py hash_eval / ot_hash_eval), torch (src/hash_eval.py) and this
+// kernel agree bit for bit.  Lets the whole native loop be checked against the CPU oracle and the
+// tree kernels be timed without a network.
+__device__ __forceinline__ uint64_t position_hash(uint64_t bb0, uint64_t bb1, bool p1_to_move)
+{
+    uint64_t x = bb0 * 0x9E3779B97F4A7C15ull;
+    x ^= (bb1 + 0x7F4A7C159E3779B9ull) * 0xBF58476D1CE4E5B9ull;
+    x += p1_to_move ? 0x94D049BB133111EBull : 0x2545F4914F6CDD1Dull;
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return x;
+}
+
+// one 64-lane wavefront per sample: lane = cell (Connect4: 42 of them), a ballot rebuilds the bitboards
+template <bool OTHELLO>
+__global__ void __launch_bounds__(256) k_hash_eval(const float *features, const uint8_t *mask, float *probs, float *wdl,
+                                                   float *ml, int64_t batch, const int32_t *rows, const int64_t *n_rows)
+{
+    constexpr int CELLS = OTHELLO ? 64 : 42, A = OTHELLO ? 65 : 7;
+    const int lane = threadIdx.x & 63;
+    const int64_t b = static_cast<int64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int64_t n = batch;
+    if (n_rows != nullptr && *n_rows < n) n = *n_rows;
+    if (b >= n) return;
+    int64_t row = rows != nullptr ? rows[b] : b;
+    if (row < 0 || row >= batch) return;
+    const float *f = features + row * 3 * CELLS;
+    const bool in = lane < CELLS;
+    const float own = in ? f[lane] : 0.0f, opp = in ? f[CELLS + lane] : 0.0f;
+    const bool p1 = f[2 * CELLS] > 0.0f;
+    // display cell -> bit of the reference's bitboards (Connect4.h:15-29: col*7 + 5-row; Othello.h:18-23: row*8+col)
+    const int bit = OTHELLO ? lane : ((lane % 7) * 7 + (5 - lane / 7));
+    const bool is_p1 = in && ((p1 && own != 0.0f) || (!p1 && opp != 0.0f));
+    const bool is_p2 = in && ((p1 && opp != 0.0f) || (!p1 && own != 0.0f));
+    uint64_t bb0 = 0, bb1 = 0;
+    if (OTHELLO) {
+        bb0 = __ballot(is_p1); bb1 = __ballot(is_p2);
+    } else {
+        // scatter the ballot's cell order into the bitboard's bit order
+        const uint64_t m1 = __ballot(is_p1), m2 = __ballot(is_p2);
+        for (int c = 0; c < 42; ++c) {
+            const int bt = (c % 7) * 7 + (5 - c / 7);
+            bb0 |= ((m1 >> c) & 1ull) << bt;
+            bb1 |= ((m2 >> c) & 1ull) << bt;
+        }
+        (void)bit;
+    }
+    const uint64_t h = position_hash(bb0, bb1, p1);
+    const uint8_t *mk = mask != nullptr ? mask + row * A : nullptr;
+    if (!OTHELLO) {
+        if (lane < 7) {
+            const float p = static_cast<float>(1 + ((h >> (4 * lane)) & 15)) / 16.0f;
+            probs[row * 7 + lane] = (mk == nullptr || mk[lane]) ? p : 0.0f;
+        }
+    } else {
+        for (int a = lane; a < 65; a += 64) {
+            const int k = a >> 4, j = a & 15;
+            uint64_t hk = h + 0x9E3779B97F4A7C15ull * static_cast<uint64_t>(k + 1);
+            hk ^= hk >> 29; hk *= 0xBF58476D1CE4E5B9ull; hk ^= hk >> 32;
+            const float p = static_cast<float>(1 + ((hk >> (4 * j)) & 15)) / 16.0f;
+            probs[row * 65 + a] = (mk == nullptr || mk[a]) ? p : 0.0f;
+        }
+    }
+    if (lane < 3) {
+        const uint64_t w0 = 1 + ((h >> 28) & 31), w1 = 1 + ((h >> 33) & 31), w2 = 1 + ((h >> 38) & 31);
+        const float tot = static_cast<float>(w0 + w1 + w2);
+        const uint64_t mine = lane == 0 ? w0 : (lane == 1 ? w1 : w2);
+        wdl[row * 3 + lane] = static_cast<float>(mine) / tot;
+    }
+    if (lane == 3) {
+        const float v = static_cast<float>((h >> 43) & 63);
+        ml[row] = OTHELLO ? (v / 32.0f - 1.0f) : (v / 2.0f);
+    }
+}
 }
 
 extern "C" {
@@ -53,10 +132,23 @@ int az_nn_model_create(const az_nn_model_weights *w, az_nn_model **out)
     return 0;
 }
 
+int az_nn_model_create_hash(int game, az_nn_model **out)
+{
+    if (out == nullptr || (game != 0 && game != 1)) return 1;
+    auto *m = new (std::nothrow) az_nn_model();
+    if (m == nullptr) return 1;
+    m->kind = game == 0 ? AZ_NN_KIND_HASH_CONNECT4 : AZ_NN_KIND_HASH_OTHELLO;
+    *out = m;
+    return 0;
+}
+
 void az_nn_model_destroy(az_nn_model *m) { delete m; }
 
-uint64_t az_nn_model_scratch_bytes(const az_nn_model *, int64_t batch)
+int az_nn_model_kind(const az_nn_model *m) { return m ? m->kind : -1; }
+
+uint64_t az_nn_model_scratch_bytes(const az_nn_model *m, int64_t batch)
 {
+    if (m != nullptr && m->kind != AZ_NN_KIND_CONNECT4_CNN) return 0;
     return batch > 0 ? static_cast<uint64_t>(2 * batch * kTokenBytes) : 0;
 }
 
@@ -66,8 +158,18 @@ int az_nn_model_forward(const az_nn_model *m, const float *features, const uint8
 {
     if (m == nullptr || features == nullptr || probs == nullptr || wdl == nullptr || moves_left == nullptr) return 1;
     if (batch <= 0) return batch == 0 ? 0 : 1;
-    if (scratch == nullptr || scratch_bytes < az_nn_model_scratch_bytes(m, batch)) return 1;
     if ((rows == nullptr) != (n_rows == nullptr)) return 1;
+    if (m->kind != AZ_NN_KIND_CONNECT4_CNN) {
+        const dim3 grid(static_cast<unsigned>((batch + 3) / 4)), block(256);
+        if (m->kind == AZ_NN_KIND_HASH_OTHELLO)
+            hipLaunchKernelGGL(k_hash_eval<true>, grid, block, 0, static_cast<hipStream_t>(stream), features, mask, probs, wdl,
+                               moves_left, batch, rows, n_rows);
+        else
+            hipLaunchKernelGGL(k_hash_eval<false>, grid, block, 0, static_cast<hipStream_t>(stream), features, mask, probs, wdl,
+                               moves_left, batch, rows, n_rows);
+        return 0;
+    }
+    if (scratch == nullptr || scratch_bytes < az_nn_model_scratch_bytes(m, batch)) return 1;
     const az_nn_model_weights &w = m->w;
     char *a = static_cast<char *>(scratch);
     char *b = a + batch * kTokenBytes;

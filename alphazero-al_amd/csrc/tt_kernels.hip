@@ -62,7 +62,7 @@ __device__ __forceinline__ uint64_t value_sum(const float *v)
 
 __global__ void __launch_bounds__(256) k_tt_lookup(LeafBuf lf, int n_leaves, TtTable t, const uint64_t *clock,
                                                    float *probs, float *wdl, float *ml, int32_t *miss_idx,
-                                                   int64_t *miss_count, uint64_t *keys)
+                                                   int64_t *miss_count, uint64_t *keys, int *err)
 {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const bool in = i < n_leaves;
@@ -101,16 +101,23 @@ __global__ void __launch_bounds__(256) k_tt_lookup(LeafBuf lf, int n_leaves, TtT
         }
     }
     base = __shfl(base, 0, 64);
-    if (miss) miss_idx[base + __popcll(mm & ((1ull << lane) - 1))] = static_cast<int32_t>(i);
+    if (miss) {
+        // the list holds n_leaves entries: a position outside it (a count that was not cleared) raises
+        // the engine's error flag instead of storing anywhere
+        const int64_t pos = base + __popcll(mm & ((1ull << lane) - 1));
+        if (pos >= 0 && pos < n_leaves) miss_idx[pos] = static_cast<int32_t>(i);
+        else atomicOr(err, ERR_LIST_OVERFLOW);
+    }
 }
 
-__global__ void __launch_bounds__(256) k_tt_insert(TtTable t, const uint64_t *clock, const int32_t *miss_idx,
+__global__ void __launch_bounds__(256) k_tt_insert(TtTable t, int n_leaves, const uint64_t *clock, const int32_t *miss_idx,
                                                    const int64_t *miss_count, const uint64_t *keys, const float *probs,
                                                    const float *wdl, const float *ml)
 {
     const int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (j >= *miss_count) return;
+    if (j >= *miss_count || j >= n_leaves) return;
     const int64_t i = miss_idx[j];
+    if (i < 0 || i >= n_leaves) return;
     const uint64_t k0 = keys[2 * i], k1 = keys[2 * i + 1];
     TtEntry e;
 #pragma unroll
@@ -143,7 +150,7 @@ __global__ void __launch_bounds__(256) k_tt_insert(TtTable t, const uint64_t *cl
 // One thread per leaf; the workgroup agrees on its share of the list through LDS, so the global
 // counter sees one atomic per workgroup (a single-workgroup scan was tried: 18 us, slower than
 // the contended atomics it was meant to avoid).
-__global__ void __launch_bounds__(1024) k_live_leaves(LeafBuf lf, int n_leaves, int32_t *idx, int64_t *count)
+__global__ void __launch_bounds__(1024) k_live_leaves(LeafBuf lf, int n_leaves, int32_t *idx, int64_t *count, int *err)
 {
     __shared__ int s_wave[16];
     __shared__ long long s_base;
@@ -164,29 +171,34 @@ __global__ void __launch_bounds__(1024) k_live_leaves(LeafBuf lf, int n_leaves, 
         s_base = total ? static_cast<long long>(atomicAdd(reinterpret_cast<unsigned long long *>(count),
                                                           static_cast<unsigned long long>(total))) : 0;
     __syncthreads();
-    if (livel) idx[s_base + before + __popcll(m & ((1ull << lane) - 1))] = static_cast<int32_t>(i);
+    if (livel) {
+        // bounded by the list's size whatever the counter held (see k_tt_lookup)
+        const long long pos = s_base + before + __popcll(m & ((1ull << lane) - 1));
+        if (pos >= 0 && pos < n_leaves) idx[pos] = static_cast<int32_t>(i);
+        else atomicOr(err, ERR_LIST_OVERFLOW);
+    }
 }
 
 }  // namespace
 
-void launch_live_leaves(LeafBuf lf, int n_leaves, int32_t *idx, int64_t *count, hipStream_t s, bool clear_count)
+void launch_live_leaves(LeafBuf lf, int n_leaves, int32_t *idx, int64_t *count, int *err, hipStream_t s, bool clear_count)
 {
     if (clear_count) (void)hipMemsetAsync(count, 0, sizeof(int64_t), s);
-    hipLaunchKernelGGL(k_live_leaves, dim3((n_leaves + 1023) / 1024), dim3(1024), 0, s, lf, n_leaves, idx, count);
+    hipLaunchKernelGGL(k_live_leaves, dim3((n_leaves + 1023) / 1024), dim3(1024), 0, s, lf, n_leaves, idx, count, err);
 }
 
 void launch_tt_lookup(LeafBuf lf, int n_leaves, TtTable t, const uint64_t *clock, float *probs, float *wdl, float *ml,
-                      int32_t *miss_idx, int64_t *miss_count, uint64_t *keys, hipStream_t s)
+                      int32_t *miss_idx, int64_t *miss_count, uint64_t *keys, int *err, hipStream_t s)
 {
     (void)hipMemsetAsync(miss_count, 0, sizeof(int64_t), s);
     hipLaunchKernelGGL(k_tt_lookup, dim3((n_leaves + 255) / 256), dim3(256), 0, s, lf, n_leaves, t, clock, probs, wdl, ml,
-                       miss_idx, miss_count, keys);
+                       miss_idx, miss_count, keys, err);
 }
 
 void launch_tt_insert(int n_leaves, TtTable t, const uint64_t *clock, const int32_t *miss_idx, const int64_t *miss_count,
                       const uint64_t *keys, const float *probs, const float *wdl, const float *ml, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_tt_insert, dim3((n_leaves + 255) / 256), dim3(256), 0, s, t, clock, miss_idx, miss_count, keys,
+    hipLaunchKernelGGL(k_tt_insert, dim3((n_leaves + 255) / 256), dim3(256), 0, s, t, n_leaves, clock, miss_idx, miss_count, keys,
                        probs, wdl, ml);
 }
 

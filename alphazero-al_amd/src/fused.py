@@ -34,6 +34,11 @@ def lib():
         vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
         L.az_last_error.restype = C.c_char_p
         L.az_mcts_dev_prepare.argtypes = [vp, i32, i64]
+        L.az_mcts_dev_prepare_stream.argtypes = [vp, i32, i64, vp]
+        L.az_mcts_dev_check.argtypes = [vp, vp]
+        L.az_mcts_dev_replay.argtypes = [vp, vp, i64, i64, vp]
+        L.az_nn_model_create_hash.argtypes = [i32, C.POINTER(vp)]
+        L.az_nn_model_destroy.argtypes = [vp]
         L.az_mcts_dev_set_roots.argtypes = [vp, vp, vp, vp, vp]
         L.az_mcts_dev_import_roots.argtypes = [vp, vp, vp, vp]
         L.az_mcts_dev_select.argtypes = [vp, i32, i32, vp, vp, vp]
@@ -148,6 +153,7 @@ class FusedSearch:
         self.table_verify = False
         self._tt_bufs = {}
         self.tt_mismatch = None
+        self._hash_model = None
 
     def _sync_fast_net(self):
         if not self.use_fast or hasattr(self.net, "predict_device"):
@@ -174,10 +180,38 @@ class FusedSearch:
         """az_nn_model* when the search can run as one native call: HIP inference twin, compact
         evaluation on, no verify pass, no graph replay asked for (AZ_FUSED_NATIVE=0 keeps the
         Python loop over the same entry points)."""
-        if (self.fast is None or self.use_graph or self.table_verify or not self.compact_eval
-                or os.environ.get("AZ_FUSED_NATIVE", "1") == "0" or self.game_name != "Connect4"):
+        if self.use_graph or self.table_verify or not self.compact_eval or os.environ.get("AZ_FUSED_NATIVE", "1") == "0":
+            return None
+        game = getattr(self.net, "native_hash_game", None)
+        if game is not None:
+            # the integer-hash evaluator has a native twin for either game (az_nn_model_create_hash)
+            if self._hash_model is None:
+                h = C.c_void_p()
+                if lib().az_nn_model_create_hash(int(game), C.byref(h)) != 0:
+                    raise RuntimeError("az_nn_model_create_hash failed")
+                self._hash_model = h
+            return self._hash_model
+        if self.fast is None or self.game_name != "Connect4":
             return None
         return self.fast.native_model()
+
+    def __del__(self):
+        try:
+            h = self.__dict__.get("_hash_model")
+            if h is not None and _LIB is not None:
+                self.__dict__["_hash_model"] = None
+                _LIB.az_nn_model_destroy(h)
+        except Exception:
+            pass
+
+    def replay(self, sym_ids=None, root_noise=None):
+        """Recorded draws instead of the device generator (az_mcts_dev_replay, parity tests):
+        sym_ids int32 tensor (n_select_calls, stride >= B*K) on the device, root_noise float32
+        (B, A) by edge index; both None ends the replay.  The tensors are kept alive here."""
+        self._replay_keep = (sym_ids, root_noise)
+        sp = sym_ids.data_ptr() if sym_ids is not None else None
+        stride, calls = (sym_ids.shape[1], sym_ids.shape[0]) if sym_ids is not None else (0, 0)
+        check(lib().az_mcts_dev_replay(self.h, sp, stride, calls, root_noise.data_ptr() if root_noise is not None else None))
 
     # ------------------------------------------------------------------ transposition table
     def enable_table(self, log2_entries=20, verify=False):
@@ -187,7 +221,8 @@ class FusedSearch:
         `verify=True` also evaluates every leaf densely and counts rows whose table value differs
         from the fresh one (`tt_mismatch`, must stay 0: the evaluator is a pure function per row)."""
         self._sync_fast_net()
-        if self.fast is None or not getattr(self.fast, "supports_compact", False):
+        native_hash = getattr(self.net, "native_hash_game", None) is not None and self._native_model() is not None
+        if not native_hash and (self.fast is None or not getattr(self.fast, "supports_compact", False)):
             raise RuntimeError("the device transposition table needs the HIP inference twin of the Connect4 network "
                                "(a module with the reference CNN's parameters on a GPU)")
         check(lib().az_mcts_dev_tt_create(self.h, int(log2_entries)))
@@ -349,7 +384,7 @@ class FusedSearch:
             # the whole schedule, evaluator included, from native code (az_mcts_dev_search)
             check(lib().az_mcts_dev_search(self.h, model, int(n_playout), K, 1 if self.table_log2 else 0, _stream()))
             return
-        check(lib().az_mcts_dev_prepare(self.h, K, int(n_playout)))
+        check(lib().az_mcts_dev_prepare_stream(self.h, K, int(n_playout), _stream()))
         if K <= 1:
             for _ in range(n_playout):
                 self._run(1, 0)

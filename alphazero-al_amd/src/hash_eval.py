@@ -23,6 +23,7 @@ class HashEvaluator(torch.nn.Module):
     mask) -> (probs[n,7], wdl_rel[n,3], moves_left[n])`, all float32 tensors on the device."""
     is_device_evaluator = True
     n_actions = 7
+    native_hash_game = 0        # AZ_GAME_CONNECT4: az_nn_model_create_hash computes the same function
 
     def __init__(self, device="cuda"):
         super().__init__()
@@ -69,6 +70,7 @@ class OthelloHashEvaluator(torch.nn.Module):
     re-mixed words, WDL from three 5-bit weights, auxiliary utility = 6 bits / 32 - 1."""
     is_device_evaluator = True
     n_actions = 65
+    native_hash_game = 1        # AZ_GAME_OTHELLO
 
     def __init__(self, device="cuda"):
         super().__init__()

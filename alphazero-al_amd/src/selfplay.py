@@ -251,6 +251,9 @@ class DeviceSelfPlay:
         self.totals += torch.stack([self._c_B, fin.sum(),
                                     (fin * (self.winner == 1)).sum(), (fin * (self.winner == -1)).sum(),
                                     (fin * (self.winner == 0)).sum()])
+        # sticky device error word (arena full, compact list overflow), polled without a stall:
+        # raises one ply after the fact instead of letting the trees thin out silently
+        F.check(L.az_mcts_dev_check(self.h, s))
         # bounded run-ahead: ~550 launches per ply would otherwise pile up without limit
         ev = torch.cuda.Event()
         ev.record()
@@ -333,10 +336,9 @@ class StreamedSelfPlay:
         from concurrent.futures import ThreadPoolExecutor
         p = next(net.parameters(), None)
         self.device = p.device if p is not None else torch.device("cuda", torch.cuda.current_device())
-        # at most three: a process has four hardware queues on ROCm and the NULL stream owns one;
-        # streams that share a queue gain nothing (and, launched thousands of kernels deep from
-        # several host threads, faulted on this software stack)
-        assert 1 <= int(streams) <= 3, "StreamedSelfPlay: 1 to 3 streams"
+        # a process has four hardware queues on ROCm and the NULL stream owns one: beyond three
+        # drivers, streams share a queue and gain little
+        assert 1 <= int(streams) <= 8, "StreamedSelfPlay: 1 to 8 streams"
         streams = max(1, min(int(streams), int(n_games)))
         base, extra = divmod(int(n_games), streams)
         self.sizes = [base + (1 if i < extra else 0) for i in range(streams)]

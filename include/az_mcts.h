@@ -123,6 +123,28 @@ int az_mcts_get_all_root_stats(az_mcts *m, float *out);
  * c_puct table, and guarantees arena room for `sims_per_tree` more simulations per tree
  * (grows the arenas if needed; synchronises). */
 int az_mcts_dev_prepare(az_mcts *m, int K, int64_t sims_per_tree);
+/* The same for a caller whose work on these trees is all on ONE stream: when the call has to look
+ * at the trees (their fill), move a buffer or refresh a table, it waits for that stream only
+ * instead of the whole device - what a driver with several engines on several streams wants. */
+int az_mcts_dev_prepare_stream(az_mcts *m, int K, int64_t sims_per_tree, void *stream);
+/* Sticky device error word, polled without stalling: enqueues a copy of the word to pinned host
+ * memory on `stream` and reports what the PREVIOUS poll brought back - AZ_ERR_CAPACITY (message
+ * in az_last_error) once an expansion found its arena full or a compact leaf list overflowed.
+ * A self-play driver calls it once per ply; az_mcts_counters reports the same word synchronously. */
+int az_mcts_dev_check(az_mcts *m, void *stream);
+/* Test hook - recorded draws instead of the device generator.  The reference draws symmetry ids
+ * and Dirichlet noise from one mt19937 in env order (BatchedMCTS.h:148-154,261-267; MCTS.h:113-132,
+ * 352-358); the device loop has a counter-based generator of its own.  To compare the device loop
+ * with the reference bit for bit, a test records what the reference (the oracle) drew and plays it
+ * back: sym_ids int32 [n_select_calls][sym_stride] in DEVICE memory - the c-th az_mcts_dev_select
+ * (or selection inside az_mcts_dev_search) after this call shows leaf `flat` under symmetry
+ * sym_ids[c*sym_stride + flat] (0 for terminal leaves; running past the tape is AZ_ERR_STATE);
+ * root_noise float [n_envs][A] in DEVICE memory, row = tree, column = EDGE index (legal moves in
+ * ascending order), already normalised - what root expansions and az_mcts_dev_prune_roots store
+ * from now on; the arrays are read when the kernels run, so update them in stream order.  Either
+ * pointer may be NULL (that part stays with the generator); both NULL ends the replay. */
+int az_mcts_dev_replay(az_mcts *m, const int32_t *sym_ids, int64_t sym_stride, int64_t n_select_calls,
+                       const float *root_noise);
 /* Root positions as bitboards already in HBM: bb_p1/bb_p2 uint64[n_envs], turn int32[n_envs]
  * (the reference passes int8 grids on every call, BatchedMCTS.h:136-137,244-245). */
 int az_mcts_dev_set_roots(az_mcts *m, const uint64_t *bb_p1, const uint64_t *bb_p2,

@@ -118,6 +118,16 @@ typedef struct az_nn_model_weights {
 } az_nn_model_weights;
 typedef struct az_nn_model az_nn_model;
 int az_nn_model_create(const az_nn_model_weights *w, az_nn_model **out);
+/* The integer-hash evaluator as a model object (game: 0 Connect4, 1 Othello - AZ_GAME_*): a pure
+ * function of the position shown by the feature planes, bit-identical to tests/scenarios.py
+ * `hash_eval` / `ot_hash_eval` and to src/hash_eval.py.  Not a network: it exists so that the whole
+ * native loop (az_mcts_dev_search) can be compared bit for bit with the CPU oracle, and so that the
+ * tree kernels can be timed with no evaluator to speak of.  Needs no scratch. */
+int az_nn_model_create_hash(int game, az_nn_model **out);
+#define AZ_NN_KIND_CONNECT4_CNN  0
+#define AZ_NN_KIND_HASH_CONNECT4 1
+#define AZ_NN_KIND_HASH_OTHELLO  2
+int az_nn_model_kind(const az_nn_model *m);
 void az_nn_model_destroy(az_nn_model *m);
 uint64_t az_nn_model_scratch_bytes(const az_nn_model *m, int64_t batch);
 int az_nn_model_forward(const az_nn_model *m, const float *features, const uint8_t *mask, float *probs,

@@ -164,6 +164,8 @@ void orc_search_rollout(orc_batch *b, const int8_t *boards, const int32_t *turns
 void orc_get_all_counts(const orc_batch *b, int32_t *out /* n_envs*7 */);
 void orc_get_all_root_stats(const orc_batch *b, float *out /* n_envs*62 */);
 
+/* oracle-only: the symmetry ids of the last search_batch (pending_sym_ids_, BatchedMCTS.h:45) */
+void orc_pending_sym(const orc_batch *b, int32_t *out /* n_envs */);
 void orc_stats_get(const orc_batch *b, orc_stats *out);
 void orc_stats_reset(orc_batch *b);
 /* pool occupancy of one tree: nodes / edges in use */
@@ -195,6 +197,7 @@ void oro_backprop_batch_vl(oro_batch *b, int K, const float *policy, const float
 void oro_search_rollout(oro_batch *b, const int8_t *boards, const int32_t *turns, int n_playout);
 void oro_get_all_counts(const oro_batch *b, int32_t *out /* n_envs*65 */);
 void oro_get_all_root_stats(const oro_batch *b, float *out /* n_envs*526 */);
+void oro_pending_sym(const oro_batch *b, int32_t *out /* n_envs */);
 void oro_stats_get(const oro_batch *b, orc_stats *out);
 void oro_stats_reset(oro_batch *b);
 void oro_tree_size(const oro_batch *b, int env, int32_t *nodes, int32_t *edges);

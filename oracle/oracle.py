@@ -82,6 +82,7 @@ def lib():
         f("search_rollout").argtypes = [vp, vp, vp, i32]
         f("get_all_counts").argtypes = [vp, vp]
         f("get_all_root_stats").argtypes = [vp, vp]
+        f("pending_sym").argtypes = [vp, vp]
         f("stats_get").argtypes = [vp, C.POINTER(OrcStats)]
         f("stats_reset").argtypes = [vp]
         f("tree_size").argtypes = [vp, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -224,7 +225,13 @@ class _Batched:
         self._f("get_all_root_stats")(self._h, _p(out))
         return out
 
-    # --- oracle-only extras (workload statistics for the roofline figures) ---
+    # --- oracle-only extras ---
+    def pending_sym_ids(self):
+        """Symmetry ids drawn by the last search_batch (pending_sym_ids_, BatchedMCTS.h:45)."""
+        out = np.empty(self.n, np.int32)
+        self._f("pending_sym")(self._h, _p(out))
+        return out
+
     def stats(self):
         s = OrcStats()
         self._f("stats_get")(self._h, C.byref(s))

@@ -190,14 +190,20 @@ class C4Game:
         return turn
 
 
-def playout(mcts, boards, turns, n_playout, K, evaluator=None, log=None, game=C4Game):
+def playout(mcts, boards, turns, n_playout, K, evaluator=None, log=None, game=C4Game, after_backprop=None):
     """The reference wrapper's loop (MCTS_cpp.py:110-357) at the mcts_cpp level, without
     cache/time budget: K<=1 -> n_playout single sims; K>1 -> one warm-up sim then VL chunks
-    of min(K, remaining)."""
+    of min(K, remaining).  `after_backprop(i)` is called after the i-th iteration's backprop."""
     n = boards.shape[0]
     A = game.A
     if evaluator is None:
         evaluator = game.hash_eval
+    it_no = [0]
+
+    def done_one():
+        if after_backprop is not None:
+            after_backprop(it_no[0])
+        it_no[0] += 1
 
     def one_plain():
         lb, td, t1, t2, it, lt, vm = mcts.search_batch(boards, turns)
@@ -211,9 +217,12 @@ def playout(mcts, boards, turns, n_playout, K, evaluator=None, log=None, game=C4
             dd, a1, a2 = rel_to_abs(wdl, lt[nt])
             d[nt], p1[nt], p2[nt], ml[nt] = dd, a1, a2, m
         if log is not None:
+            # the ids of a plain search stay inside the native object (pending_sym_ids_); the oracle can show them
+            sy = mcts.pending_sym_ids() if hasattr(mcts, "pending_sym_ids") else None
             log.append(dict(kind="plain", is_term=it.copy(), turns=lt.copy(), boards=lb.copy(),
-                            mask=vm.copy(), term=np.stack([td, t1, t2], 1)))
+                            mask=vm.copy(), term=np.stack([td, t1, t2], 1), plain_sym=sy))
         mcts.backprop_batch(probs, d, p1, p2, ml, it)
+        done_one()
 
     if K <= 1:
         for _ in range(n_playout):
@@ -241,6 +250,7 @@ def playout(mcts, boards, turns, n_playout, K, evaluator=None, log=None, game=C4
             log.append(dict(kind="vl", is_term=it.copy(), turns=lt.copy(), boards=lb.copy(),
                             mask=vm.copy(), sym=sy.copy(), term=np.stack([td, t1, t2], 1)))
         mcts.backprop_batch_vl(k, probs, d, p1, p2, ml, it, sy)
+        done_one()
 
 
 def counts_of(mcts, n, A=7):

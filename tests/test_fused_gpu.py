@@ -55,7 +55,10 @@ def _oracle_plies(cfg, boards, turns, n, K, plies):
 
 
 def _fused_plies(env, cfg, boards, turns, n, K, plies, graph):
-    os.environ["AZ_FUSED_GRAPH"] = "1" if graph else "0"
+    """graph: True = hipGraph replay of the Python loop, False = the Python loop issued call by call,
+    "native" = the whole schedule from native code (az_mcts_dev_search with the hash model)."""
+    os.environ["AZ_FUSED_GRAPH"] = "1" if graph is True else "0"
+    os.environ["AZ_FUSED_NATIVE"] = "1" if graph == "native" else "0"
     try:
         B = boards.shape[0]
         w = env["W"].BatchedMCTS(B, c_init=cfg["c_init"], c_base=cfg["c_base"], alpha=cfg["dirichlet_alpha"],
@@ -79,9 +82,10 @@ def _fused_plies(env, cfg, boards, turns, n, K, plies, graph):
         return np.stack(counts), np.stack(stats)
     finally:
         os.environ.pop("AZ_FUSED_GRAPH", None)
+        os.environ.pop("AZ_FUSED_NATIVE", None)
 
 
-@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("graph", [False, True, "native"])
 @pytest.mark.parametrize("n,K", [(50, 4), (200, 4), (37, 1), (66, 8)])
 def test_fused_path_bit_exact_vs_oracle(env, graph, n, K):
     rng = np.random.default_rng(n * 10 + K)
