@@ -997,12 +997,13 @@ def test_native_search_refuses_misuse_and_reservation_is_sized(env):
     net = env["N"].Connect4Net(device="cuda").eval()
     env["N"].load_reference_weights(net, {k: wts[k] for k in wts.files})
     from src.fast_net import FastConnect4Net
-    model = FastConnect4Net.from_module(net).native_model()
+    twin = FastConnect4Net.from_module(net)          # owns the model object: keep it alive
+    model = twin.native_model()
     assert model is not None
     assert L.az_mcts_dev_search(h, model, 16, 4, 1, s) != 0 and b"table" in L.az_last_error()
     assert L.az_mcts_dev_search(h, model, 16, 0, 0, s) != 0
     wo = env["W"].BatchedMCTS(64, 1.4, 400, 0.3, 16, game_name="Othello")
-    assert L.az_mcts_dev_search(F.C.c_void_p(wo.mcts.handle), model, 16, 4, 0, s) != 0 and b"Connect4" in L.az_last_error()
+    assert L.az_mcts_dev_search(F.C.c_void_p(wo.mcts.handle), model, 16, 4, 0, s) != 0 and b"does not belong" in L.az_last_error()
     assert L.az_mcts_dev_search(h, model, 0, 4, 0, s) == 0                      # nothing to do is not an error
     torch.cuda.synchronize()
     sp = env["SP"].DeviceSelfPlay(env["H"].HashEvaluator("cuda"), 512, n_playout=100, vl_batch=4)
