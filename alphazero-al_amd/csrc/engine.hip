@@ -186,6 +186,12 @@ struct az_mcts {
     DevBuf<uint8_t> ev_mask, ev_scratch;
     DevBuf<int32_t> ev_rows;
     DevBuf<int64_t> ev_nrows;
+    // one chunk of az_mcts_dev_tt_refresh
+    DevBuf<float> rf_feat, rf_probs, rf_wdl, rf_ml;
+    DevBuf<uint8_t> rf_mask, rf_scratch;
+    DevBuf<int32_t> rf_rows;
+    DevBuf<int64_t> rf_count;
+    DevBuf<uint64_t> rf_keys;
     bool profiling = false;
     int profile_stride = 1;      // time every profile_stride-th launch of a kind
     int64_t profile_seen[2] = {0, 0};
@@ -1015,6 +1021,38 @@ int az_mcts_dev_tt_insert(az_mcts *m, int K, const int32_t *miss_idx, const int6
         az::TtTable t{m->tt_entries.p, m->tt_mask, m->tt_stats.p};
         az::launch_tt_insert(static_cast<int>(total), t, m->call_ctr.p, miss_idx, miss_count, m->tt_keys.p, probs, wdl_rel,
                              moves_left, static_cast<hipStream_t>(stream));
+    });
+}
+
+int az_mcts_dev_tt_refresh(az_mcts *m, const az_nn_model *model, void *stream)
+{
+    return guarded([&] {
+        require(m->tt_entries.p != nullptr, "dev_tt_refresh: no table (az_mcts_dev_tt_create)");
+        require(model != nullptr, "dev_tt_refresh: no evaluator model");
+        const int kind = az_nn_model_kind(model);
+        require(kind == AZ_NN_KIND_CONNECT4_CNN || kind == AZ_NN_KIND_HASH_CONNECT4, "dev_tt_refresh: not a Connect4 evaluator");
+        HIP_OK(hipSetDevice(m->device));
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        const int64_t chunk = 16384;
+        const size_t scratch = az_nn_model_scratch_bytes(model, chunk);
+        if (m->rf_rows.n < static_cast<size_t>(chunk) || m->rf_scratch.n < scratch) {
+            HIP_OK(hipStreamSynchronize(s));
+            m->rf_feat.ensure(chunk * 126); m->rf_mask.ensure(chunk * 7); m->rf_probs.ensure(chunk * 7);
+            m->rf_wdl.ensure(chunk * 3); m->rf_ml.ensure(chunk); m->rf_rows.ensure(chunk); m->rf_keys.ensure(2 * chunk);
+            m->rf_count.ensure(1, true); m->rf_scratch.ensure(scratch);
+        }
+        az::TtTable t{m->tt_entries.p, m->tt_mask, m->tt_stats.p};
+        const int64_t entries = static_cast<int64_t>(m->tt_mask) + 1;
+        for (int64_t e0 = 0; e0 < entries; e0 += chunk) {
+            const int n = static_cast<int>(std::min<int64_t>(chunk, entries - e0));
+            az::launch_tt_refresh_gather(t, static_cast<uint64_t>(e0), n, m->rf_feat.p, m->rf_mask.p, m->rf_rows.p, m->rf_count.p,
+                                         m->rf_keys.p, s);
+            if (az_nn_model_forward(model, m->rf_feat.p, m->rf_mask.p, m->rf_probs.p, m->rf_wdl.p, m->rf_ml.p, n, m->rf_rows.p,
+                                    m->rf_count.p, m->rf_scratch.p, m->rf_scratch.n, stream) != 0)
+                throw AzError(AZ_ERR_ARG, "dev_tt_refresh: az_nn_model_forward refused its arguments");
+            az::launch_tt_refresh_store(t, static_cast<uint64_t>(e0), n, m->rf_rows.p, m->rf_count.p, m->rf_keys.p, m->rf_probs.p,
+                                        m->rf_wdl.p, m->rf_ml.p, s);
+        }
     });
 }
 

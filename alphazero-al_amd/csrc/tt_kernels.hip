@@ -145,6 +145,84 @@ __global__ void __launch_bounds__(256) k_tt_insert(TtTable t, int n_leaves, cons
     if (replaced) atomicAdd(&t.stats[3], 1ull);
 }
 
+// ---- refresh: every resident key evaluated again (MCTS_cpp.py:361-377 `refresh_cache`, which the
+// reference calls after a weight update so that the table keeps its keys and loses no warmth).
+// Pass 1 decodes the entries [e0, e0 + n) - the key comes back by XORing with the value's checksum -
+// and writes, for every resident one, the evaluator's input exactly as it was when the entry was
+// made (the stored frame IS the evaluator's frame): relative planes, action mask, its row in the
+// compact list.  The evaluator runs on that list.  Pass 2 stores the fresh values under the same
+// keys.  An entry torn by an earlier race decodes to an implausible position and is emptied.
+__device__ __forceinline__ bool plausible_c4(uint64_t own, uint64_t opp)
+{
+    constexpr uint64_t BOTTOM = 0x0000040810204081ull;                // bit 0 of every column
+    constexpr uint64_t SENT = BOTTOM << 6;                            // bit 6 of every column: never a stone
+    constexpr uint64_t BOARD = (1ull << 49) - 1;
+    const uint64_t occ = own | opp;
+    if ((own & opp) || (occ & SENT) || (occ & ~BOARD)) return false;
+    return ((occ + BOTTOM) & occ) == 0;                               // every column filled from the bottom, no gaps
+}
+
+__global__ void __launch_bounds__(256) k_tt_refresh_gather(TtTable t, uint64_t e0, int n, float *features, uint8_t *mask,
+                                                           int32_t *rows, int64_t *count, uint64_t *keys)
+{
+    const int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    bool live = false;
+    if (j < n) {
+        TtEntry e = t.e[e0 + j];
+        if (e.k0 != 0 || e.k1 != 0) {
+            const uint64_t c = value_sum(e.v);
+            const uint64_t k0 = e.k0 ^ c, k1 = e.k1 ^ (c << 17 | c >> 47);
+            const uint64_t own = k0 & ~(1ull << 63), opp = k1 & ~(1ull << 62);
+            if ((k1 >> 62) == 1ull && plausible_c4(own, opp)) {
+                live = true;
+                keys[2 * j] = k0; keys[2 * j + 1] = k1;
+                const float side = (k0 >> 63) ? 1.0f : -1.0f;
+                float *f = features + j * 126;
+                for (int cell = 0; cell < 42; ++cell) {
+                    const int bit = (cell % 7) * 7 + (5 - cell / 7);
+                    f[cell] = ((own >> bit) & 1ull) ? 1.0f : 0.0f;
+                    f[42 + cell] = ((opp >> bit) & 1ull) ? 1.0f : 0.0f;
+                    f[84 + cell] = side;
+                }
+                for (int a = 0; a < 7; ++a) mask[j * 7 + a] = (((own | opp) >> (a * 7 + 5)) & 1ull) ? 0 : 1;
+            } else {
+                TtEntry z{};                                          // unreadable: empty it
+                t.e[e0 + j] = z;
+            }
+        }
+    }
+    const unsigned long long m = __ballot(live);
+    const int lane = threadIdx.x & 63;
+    long long base = 0;
+    if (lane == 0 && m) base = static_cast<long long>(atomicAdd(reinterpret_cast<unsigned long long *>(count),
+                                                                static_cast<unsigned long long>(__popcll(m))));
+    base = __shfl(base, 0, 64);
+    if (live) {
+        const long long pos = base + __popcll(m & ((1ull << lane) - 1));
+        if (pos >= 0 && pos < n) rows[pos] = static_cast<int32_t>(j);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_tt_refresh_store(TtTable t, uint64_t e0, int n, const int32_t *rows,
+                                                          const int64_t *count, const uint64_t *keys, const float *probs,
+                                                          const float *wdl, const float *ml)
+{
+    const int64_t q = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (q >= *count || q >= n) return;
+    const int64_t j = rows[q];
+    if (j < 0 || j >= n) return;
+    TtEntry e;
+#pragma unroll
+    for (int a = 0; a < 7; ++a) e.v[a] = probs[j * 7 + a];
+    e.v[7] = wdl[j * 3 + 0]; e.v[8] = wdl[j * 3 + 1]; e.v[9] = wdl[j * 3 + 2];
+    e.v[10] = ml[j];
+    const uint64_t c = value_sum(e.v);
+    e.k0 = keys[2 * j] ^ c;
+    e.k1 = keys[2 * j + 1] ^ (c << 17 | c >> 47);
+    e.stamp = t.e[e0 + j].stamp;                                      // age is not changed by a refresh
+    t.e[e0 + j] = e;
+}
+
 // The leaves an evaluator has to see: everything but terminal leaves, whose value comes from the
 // game (the reference's wrapper calls `predict` on the non-terminal rows only, MCTS_cpp.py:275-297).
 // One thread per leaf; the workgroup agrees on its share of the list through LDS, so the global
@@ -185,6 +263,19 @@ void launch_live_leaves(LeafBuf lf, int n_leaves, int32_t *idx, int64_t *count, 
 {
     if (clear_count) (void)hipMemsetAsync(count, 0, sizeof(int64_t), s);
     hipLaunchKernelGGL(k_live_leaves, dim3((n_leaves + 1023) / 1024), dim3(1024), 0, s, lf, n_leaves, idx, count, err);
+}
+
+void launch_tt_refresh_gather(TtTable t, uint64_t e0, int n, float *features, uint8_t *mask, int32_t *rows, int64_t *count,
+                              uint64_t *keys, hipStream_t s)
+{
+    (void)hipMemsetAsync(count, 0, sizeof(int64_t), s);
+    hipLaunchKernelGGL(k_tt_refresh_gather, dim3((n + 255) / 256), dim3(256), 0, s, t, e0, n, features, mask, rows, count, keys);
+}
+
+void launch_tt_refresh_store(TtTable t, uint64_t e0, int n, const int32_t *rows, const int64_t *count, const uint64_t *keys,
+                             const float *probs, const float *wdl, const float *ml, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_tt_refresh_store, dim3((n + 255) / 256), dim3(256), 0, s, t, e0, n, rows, count, keys, probs, wdl, ml);
 }
 
 void launch_tt_lookup(LeafBuf lf, int n_leaves, TtTable t, const uint64_t *clock, float *probs, float *wdl, float *ml,

@@ -318,11 +318,13 @@ class BatchedMCTS:
 
     def refresh_cache(self, pv_func):
         """Re-evaluate every cached position after a weight update (MCTS_cpp.py:361-377).  The
-        device table of the fused path is emptied instead: its entries are re-evaluated when the
-        search meets them again."""
+        device table of the fused path does the same in HBM (az_mcts_dev_tt_refresh: every resident
+        key evaluated again with the module's current weights, keys and ages kept)."""
         if self._fused is not None and self._fused.table_log2:
-            from src import fused as _fused
-            _fused.check(_fused.lib().az_mcts_dev_tt_clear(self._fused.h, _fused._stream()))
+            seen = self._fused._fast_version
+            self._fused._sync_fast_net()            # new snapshot of the weights; refreshes if they changed
+            if self._fused._fast_version == seen:
+                self._fused.refresh_table()
         if self.cache is None or len(self.cache) == 0:
             return self
         if hasattr(pv_func, 'score_scale'):

@@ -66,6 +66,7 @@ def lib():
         L.az_mcts_dev_tt_lookup.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
         L.az_mcts_dev_tt_insert.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
         L.az_mcts_dev_tt_stats.argtypes = [vp, C.POINTER(i64 * 4)]
+        L.az_mcts_dev_tt_refresh.argtypes = [vp, vp, vp]
         _LIB = L
     return _LIB
 
@@ -174,7 +175,7 @@ class FusedSearch:
             self._graphs.clear()        # captured graphs hold the old weight buffers
             self._eager_runs.clear()
             if self.table_log2:         # cached outputs belong to the old weights (MCTS_cpp.py:361-377)
-                check(lib().az_mcts_dev_tt_clear(self.h, _stream()))
+                self.refresh_table()
 
     def _native_model(self):
         """az_nn_model* when the search can run as one native call: HIP inference twin, compact
@@ -231,6 +232,22 @@ class FusedSearch:
         self.tt_mismatch = torch.zeros((), dtype=torch.int64, device=self.device)
         self._graphs.clear()
         self._eager_runs.clear()
+
+    def refresh_table(self):
+        """`refresh_cache` of the reference's wrapper (MCTS_cpp.py:361-377) for the device table: every
+        resident key is evaluated again with the current weights; evaluators without a native model
+        object get an empty table instead."""
+        if not self.table_log2:
+            return
+        model = None
+        if getattr(self.net, "native_hash_game", None) is not None:
+            model = self._native_model()
+        elif self.fast is not None and hasattr(self.fast, "native_model"):
+            model = self.fast.native_model()
+        if model is not None:
+            check(lib().az_mcts_dev_tt_refresh(self.h, model, _stream()))
+        else:
+            check(lib().az_mcts_dev_tt_clear(self.h, _stream()))
 
     def table_stats(self):
         arr = (C.c_int64 * 4)()

@@ -246,6 +246,10 @@ int az_mcts_dev_tt_lookup(az_mcts *m, int K, float *probs, float *wdl_rel, float
                           int64_t *miss_count, void *stream);
 int az_mcts_dev_tt_insert(az_mcts *m, int K, const int32_t *miss_idx, const int64_t *miss_count, const float *probs,
                           const float *wdl_rel, const float *moves_left, void *stream);
+/* refresh_cache (MCTS_cpp.py:361-377): after a weight update every resident key is evaluated
+ * again with `model` (include/az_nn.h) and keeps its place and age; entries that do not decode to
+ * a position are emptied.  Enqueued on `stream` in chunks of 16384 entries. */
+int az_mcts_dev_tt_refresh(az_mcts *m, const struct az_nn_model *model, void *stream);
 int az_mcts_dev_tt_stats(az_mcts *m, int64_t out[4]);
 
 /* ---- capacity / instrumentation ------------------------------------------------------- */

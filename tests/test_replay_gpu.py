@@ -96,7 +96,8 @@ def oracle_with_tape(game, make, cfg, boards, turns, n, K, plies, seed):
     return tape
 
 
-def device_loop_with_tape(env, game_name, cfg, boards, turns, n, K, plies, tape, native, follow_tape=True):
+def device_loop_with_tape(env, game_name, cfg, boards, turns, n, K, plies, tape, native, follow_tape=True, table_log2=0,
+                          table_stats=None):
     """The calls DeviceSelfPlay makes per ply (selfplay.py `step`), fed the oracle's draws."""
     torch, F = env["torch"], env["F"]
     game = S.C4Game if game_name == "Connect4" else S.OthelloGame
@@ -115,6 +116,8 @@ def device_loop_with_tape(env, game_name, cfg, boards, turns, n, K, plies, tape,
         net = (env["H"].HashEvaluator if game_name == "Connect4" else env["H"].OthelloHashEvaluator)("cuda")
         fs = F.FusedSearch(w, net)
         assert (fs._native_model() is not None) == native
+        if table_log2:
+            fs.enable_table(table_log2)
         L, h = F.lib(), fs.h
         A = game.A
         counts = torch.zeros((B, A), dtype=torch.int32, device="cuda")
@@ -140,6 +143,8 @@ def device_loop_with_tape(env, game_name, cfg, boards, turns, n, K, plies, tape,
             for i in range(B):
                 turns[i] = game.advance(boards[i], int(turns[i]), int(acts[i]))
         fs.replay(None, None)
+        if table_stats is not None:
+            table_stats.update(fs.table_stats())
         F.check(L.az_mcts_dev_check(h, F._stream()))
         torch.cuda.synchronize()
         F.check(L.az_mcts_dev_check(h, F._stream()))
@@ -226,3 +231,97 @@ def test_replay_comparison_is_sensitive(env):
     wrong["noise_search"][0][nz] = np.nextafter(wrong["noise_search"][0][nz], np.float32(2.0))
     _, s3 = device_loop_with_tape(env, "Connect4", cfg, boards, turns, n, K, 1, wrong, True, follow_tape=False)
     assert not np.array_equal(bits(s3), bits(stats))
+
+
+# ---------------------------------------------------------------------------- transposition table (f2, BASELINE config 5)
+
+def test_table_on_equals_oracle(env):
+    """The device transposition table against the ORACLE (not against the same engine without it):
+    actor configuration with symmetry - the key is the mirrored leaf as the evaluator sees it
+    (MCTS_cpp.py:150, Cache.py) - replayed draws, hash evaluator, 256 trees of which 64 share a
+    position (transpositions across trees), a table small enough for replacement to happen."""
+    rng = np.random.default_rng(31)
+    boards, turns = S.random_openings(rng, 256, 14)
+    boards[:64] = boards[0]; turns[:64] = turns[0]
+    n, K = 80, 4
+    cfg = dict(S.ACTOR_CFG, c_base=5.0 * n)
+    tape = oracle_with_tape(S.C4Game, O.BatchedMCTS_Connect4, cfg, boards, turns, n, K, 4, seed=8)
+    for log2 in (12, 18):
+        st = {}
+        counts, stats = device_loop_with_tape(env, "Connect4", cfg, boards, turns, n, K, 4, tape, True, table_log2=log2, table_stats=st)
+        _compare(tape, counts, stats)
+        assert st["hits"] > 0 and st["inserts"] > 0 and (log2 != 12 or st["replaced"] > 0), st
+
+
+@pytest.mark.parametrize("games,plies", [(2048, 3), (16384, 1)])
+def test_config5_full_size_table_equals_oracle(env, games, plies):
+    """BASELINE config 5 at its own sizes - symmetry on, table of 2^20 entries, 2048 games (one
+    GPU's share of 16384) and 16384 games on one GPU, n_playout 200, K 4 - through the native loop
+    with the table, bit-exact against the oracle on every tree (replayed draws, hash evaluator)."""
+    rng = np.random.default_rng(games)
+    b, t = S.random_openings(rng, 512, 16)
+    boards = np.tile(b, (games // 512, 1, 1)); turns = np.tile(t, games // 512)
+    n, K = 200, 4
+    cfg = dict(S.ACTOR_CFG, c_base=5.0 * n)
+    tape = oracle_with_tape(S.C4Game, O.BatchedMCTS_Connect4, cfg, boards, turns, n, K, plies, seed=games % 1000)
+    st = {}
+    counts, stats = device_loop_with_tape(env, "Connect4", cfg, boards, turns, n, K, plies, tape, True, table_log2=20, table_stats=st)
+    _compare(tape, counts, stats)
+    assert (stats[:, :, 0] == n).all() or plies > 1          # every root saw n_playout visits in the first ply
+    assert st["hit_rate"] > 0.2, st
+
+
+def test_config5_network_table_verify_and_refresh(env):
+    """With the reference network's HIP twin at config 5's per-GPU size (2048 games, 2^20 entries,
+    symmetry on): verify mode evaluates every leaf densely beside the table path and must find no
+    differing row; after a weight update `refresh_cache` (MCTS_cpp.py:361-377) re-evaluates the
+    resident keys in place - the next search hits them and still finds no differing row, and a
+    table that was NOT refreshed is caught by the same check."""
+    torch = env["torch"]
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_oracle_golden import load
+    from src import az_net
+    wts = load("g7_checkpoint_weights")
+    net = az_net.Connect4Net(device="cuda").eval()
+    az_net.load_reference_weights(net, {k: wts[k] for k in wts.files})
+    rng = np.random.default_rng(5)
+    b, t = S.random_openings(rng, 256, 12)
+    boards = np.tile(b, (8, 1, 1)); turns = np.tile(t, 8)
+    os.environ["AZ_FUSED_GRAPH"] = "0"
+    try:
+        w = env["W"].BatchedMCTS(2048, 1.4, 1000, 0.3, 200, noise_epsilon=0.25, fpu_reduction=0.2, use_symmetry=True,
+                                 mlh_slope=0.1, cache_size=1000000)
+        w.seed(11)
+        fs = w._fused_runner(net, True)
+        assert fs.table_log2 == 20
+        fs.enable_table(20, verify=True)
+        w.batch_playout(net, boards, turns, vl_batch=4, fused=True)
+        st = fs.table_stats()
+        assert st["mismatches"] == 0 and st["hit_rate"] > 0.3, st
+        inserts0 = st["inserts"]
+        # new weights: a stale table must be noticed by the verify pass ...
+        with torch.no_grad():
+            for p in net.parameters():
+                p.mul_(1.03)
+        fs.fast = None; fs._fast_version = None                  # snapshot the new weights WITHOUT touching the table
+        table_log2, fs.table_log2 = fs.table_log2, 0
+        fs._sync_fast_net()
+        fs.table_log2 = table_log2
+        for i in range(2048):
+            w.mcts.reset_env(i)
+        w.batch_playout(net, boards, turns, vl_batch=4, fused=True)
+        stale = fs.table_stats()
+        assert stale["mismatches"] > 0, "the verify pass did not notice outputs of the old weights"
+        # ... and refresh_cache repairs it in place: same keys, fresh values, no new inserts needed
+        fs.tt_mismatch.zero_()
+        w.refresh_cache(net)
+        before = fs.table_stats()
+        for i in range(2048):
+            w.mcts.reset_env(i)
+        w.batch_playout(net, boards, turns, vl_batch=4, fused=True)
+        after = fs.table_stats()
+        assert after["mismatches"] == 0, after
+        assert after["hits"] - before["hits"] > 0.5 * (after["lookups"] - before["lookups"]), (before, after)
+        assert inserts0 > 0
+    finally:
+        os.environ.pop("AZ_FUSED_GRAPH", None)
