@@ -19,6 +19,7 @@
 #include "az_nn.h"
 #include "host_rng.h"
 #include "kernels.h"
+#include "games.h"
 
 namespace {
 
@@ -680,37 +681,126 @@ int az_mcts_backprop_batch_vl(az_mcts *m, int K, const float *policy, const floa
     });
 }
 
+}  // extern "C"
+
+namespace {
+// RolloutEvaluator::evaluate_single (RolloutEvaluator.h:23-48) on the host: result of a uniformly
+// random playout from `s` - 0 draw, 1 P1 wins, 2 P2 wins - with one uniform_int(0, nv-1) draw per move
+template <class G>
+int host_playout(az::GameState s, az::HostRng &rng)
+{
+    for (;;) {
+        const int res = G::result(s);
+        if (res >= 0) return res;
+        const int nv = G::num_valid(s);
+        if (nv <= 0) return 0;
+        G::step(s, G::nth_valid(s, rng.uniform_int(nv - 1)));
+    }
+}
+
+void rollout_common_begin(az_mcts *m, const int8_t *boards, const int32_t *turns, int64_t n, int n_playout, hipStream_t s)
+{
+    require(n == m->B, "search: input_boards batch size (" + std::to_string(n) + ") must match n_envs (" +
+                           std::to_string(m->B) + ")");
+    require(n_playout >= 0, "search: n_playout must be >= 0");
+    HIP_OK(hipSetDevice(m->device));
+    const int B = m->B;
+    const int A = m->geo.actions, CELLS = m->geo.cells;
+    m->flush_resets(s);
+    m->io_boards_in.ensure(static_cast<size_t>(B) * CELLS);
+    m->io_turns_in.ensure(B);
+    HIP_OK(hipMemcpy(m->io_boards_in.p, boards, static_cast<size_t>(B) * CELLS, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(m->io_turns_in.p, turns, sizeof(int32_t) * B, hipMemcpyHostToDevice));
+    az::launch_import(m->game, m->io_boards_in.p, m->io_turns_in.p, m->roots(), B, s);
+    m->plain_leaf.ensure(B);
+    HIP_OK(hipMemset(m->plain_leaf.sym.p, 0, sizeof(int32_t) * B));
+    m->io_policy.ensure(static_cast<size_t>(B) * A); m->io_d.ensure(B); m->io_p1.ensure(B);
+    m->io_p2.ensure(B); m->io_ml.ensure(B); m->io_is_term.ensure(B);
+    m->ensure_room(static_cast<int64_t>(n_playout) * A);
+    m->last_select_vl = false;
+}
+}  // namespace
+
+extern "C" {
+
+// BatchedMCTS::search with RolloutEvaluator (BatchedMCTS.h:339-407, RolloutEvaluator.h:23-48) in the
+// REFERENCE'S random stream: per playout, selection on the device; then the playout moves of the
+// non-terminal leaves in env order and the root-noise rows of the expansions in env order, both from
+// the host mt19937 exactly as the reference (OMP_NUM_THREADS=1) consumes them; expansion and backup on
+// the device.  Bit-exact against the reference (fixture G9); one host round trip per playout.
 int az_mcts_search_rollout(az_mcts *m, const int8_t *boards, const int32_t *turns, int64_t n, int n_playout)
 {
-    // BatchedMCTS::search (BatchedMCTS.h:339-407): n_playout x { simulate, evaluate the
-    // non-terminal leaves by random playout, backprop } with no symmetry and no virtual loss,
-    // the whole loop on the device.  Playout moves and root noise use the device generator
-    // (the reference draws them from per-thread engines, so its stream is thread-count
-    // dependent anyway).
     return guarded([&] {
-        require(n == m->B, "search: input_boards batch size (" + std::to_string(n) + ") must match n_envs (" +
-                               std::to_string(m->B) + ")");
-        require(n_playout >= 0, "search: n_playout must be >= 0");
-        HIP_OK(hipSetDevice(m->device));
-        const int B = m->B;
-        const int A = m->geo.actions, CELLS = m->geo.cells;
         hipStream_t s = nullptr;
-        m->flush_resets(s);
-        m->io_boards_in.ensure(static_cast<size_t>(B) * CELLS);
-        m->io_turns_in.ensure(B);
-        HIP_OK(hipMemcpy(m->io_boards_in.p, boards, static_cast<size_t>(B) * CELLS, hipMemcpyHostToDevice));
-        HIP_OK(hipMemcpy(m->io_turns_in.p, turns, sizeof(int32_t) * B, hipMemcpyHostToDevice));
-        az::launch_import(m->game, m->io_boards_in.p, m->io_turns_in.p, m->roots(), B, s);
-        m->plain_leaf.ensure(B);
-        HIP_OK(hipMemset(m->plain_leaf.sym.p, 0, sizeof(int32_t) * B));
-        m->io_policy.ensure(static_cast<size_t>(B) * A); m->io_d.ensure(B); m->io_p1.ensure(B);
-        m->io_p2.ensure(B); m->io_ml.ensure(B); m->io_is_term.ensure(B);
-        m->ensure_room(static_cast<int64_t>(n_playout) * A);
+        rollout_common_begin(m, boards, turns, n, n_playout, s);
+        const int B = m->B, A = m->geo.actions;
+        const az::SearchParams p = m->params();
+        m->io_noise.ensure(static_cast<size_t>(B) * A, true);
+        az::EvalIn in{};
+        in.policy = m->io_policy.p; in.d = m->io_d.p; in.p1w = m->io_p1.p; in.p2w = m->io_p2.p;
+        in.is_term = m->io_is_term.p; in.moves_left = m->io_ml.p; in.sym = nullptr; in.root_noise = m->io_noise.p;
+        HIP_OK(hipMemset(m->io_ml.p, 0, sizeof(float) * B));
+        std::vector<uint8_t> flags(B), nvalid(B), is_term(B);
+        std::vector<uint64_t> bb0(B), bb1(B);
+        std::vector<int32_t> turn(B), aux(B);
+        std::vector<float> pol(static_cast<size_t>(B) * A), d(B), p1(B), p2(B), noise(static_cast<size_t>(B) * A);
+        LeafStore &ls = m->plain_leaf;
+        for (int it = 0; it < n_playout; ++it) {
+            az::launch_select(m->game, m->arena(), m->roots(), ls.view(), p, 1, false, m->counters.p, s);
+            HIP_OK(hipMemcpy(flags.data(), ls.flags.p, B, hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(nvalid.data(), ls.nvalid.p, B, hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(bb0.data(), ls.bb0.p, sizeof(uint64_t) * B, hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(bb1.data(), ls.bb1.p, sizeof(uint64_t) * B, hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(turn.data(), ls.turn.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(aux.data(), ls.aux.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
+            // phase 2: evaluate_batch over the non-terminal leaves, in order
+            for (int i = 0; i < B; ++i) {
+                const bool term = (flags[i] & az::LEAF_TERMINAL) != 0;
+                int code = (flags[i] >> az::LEAF_RESULT_SHIFT) & 3;
+                if (!term) {
+                    az::GameState st{bb0[i], bb1[i], turn[i], aux[i]};
+                    code = m->game == AZ_GAME_OTHELLO ? host_playout<az::OthelloDev>(st, m->rng)
+                                                      : host_playout<az::Connect4Dev>(st, m->rng);
+                }
+                is_term[i] = term ? 1 : 0;
+                d[i] = code == 0 ? 1.0f : 0.0f; p1[i] = code == 1 ? 1.0f : 0.0f; p2[i] = code == 2 ? 1.0f : 0.0f;
+                std::fill(pol.begin() + static_cast<size_t>(i) * A, pol.begin() + static_cast<size_t>(i + 1) * A, term ? 0.0f : 1.0f);
+            }
+            // phase 3: root expansions draw their noise in env order (MCTS.h:347-363)
+            bool any_noise = false;
+            if (m->cfg.dirichlet_alpha > 0.0f)
+                for (int i = 0; i < B; ++i)
+                    if ((flags[i] & az::LEAF_ROOT_UNEXPANDED) && !is_term[i]) {
+                        m->rng.dirichlet(m->cfg.dirichlet_alpha, &noise[static_cast<size_t>(i) * A], nvalid[i]);
+                        any_noise = true;
+                    }
+            if (any_noise) HIP_OK(hipMemcpy(m->io_noise.p, noise.data(), sizeof(float) * noise.size(), hipMemcpyHostToDevice));
+            HIP_OK(hipMemcpy(m->io_policy.p, pol.data(), sizeof(float) * pol.size(), hipMemcpyHostToDevice));
+            HIP_OK(hipMemcpy(m->io_d.p, d.data(), sizeof(float) * B, hipMemcpyHostToDevice));
+            HIP_OK(hipMemcpy(m->io_p1.p, p1.data(), sizeof(float) * B, hipMemcpyHostToDevice));
+            HIP_OK(hipMemcpy(m->io_p2.p, p2.data(), sizeof(float) * B, hipMemcpyHostToDevice));
+            HIP_OK(hipMemcpy(m->io_is_term.p, is_term.data(), B, hipMemcpyHostToDevice));
+            az::launch_backprop(m->game, m->arena(), ls.view(), p, 1, false, false, in, m->counters.p, m->err.p, s);
+        }
+        m->select_launches += n_playout;
+        m->backprop_launches += n_playout;
+        HIP_OK(hipStreamSynchronize(s));
+        m->check_device_error();
+    });
+}
+
+// The same search with the playouts on the device (k_rollout: one thread per tree, moves and root noise
+// from the device generator): no host round trip inside the loop, same distribution, a different stream.
+int az_mcts_search_rollout_dev(az_mcts *m, const int8_t *boards, const int32_t *turns, int64_t n, int n_playout)
+{
+    return guarded([&] {
+        hipStream_t s = nullptr;
+        rollout_common_begin(m, boards, turns, n, n_playout, s);
+        const int B = m->B;
         const az::SearchParams p = m->params();
         az::EvalIn in{};
         in.policy = m->io_policy.p; in.d = m->io_d.p; in.p1w = m->io_p1.p; in.p2w = m->io_p2.p;
         in.is_term = m->io_is_term.p; in.moves_left = m->io_ml.p; in.sym = nullptr; in.root_noise = nullptr;
-        m->last_select_vl = false;
         for (int it = 0; it < n_playout; ++it) {
             az::launch_select(m->game, m->arena(), m->roots(), m->plain_leaf.view(), p, 1, false, m->counters.p, s);
             az::launch_rollout(m->game, m->plain_leaf.view(), p, B, m->io_policy.p, m->io_d.p, m->io_p1.p, m->io_p2.p,

@@ -5,6 +5,8 @@
 // moves in edge order, the evaluator-frame symmetry maps, and the game-specific auxiliary
 // terms of the reference (`compute_aux_utility`, `terminal_aux`, per-ply change of the
 // auxiliary value).  Positions are two u64 bitboards + side to move + one small integer.
+// The rules are plain integer code, usable from host code as well (the reference-stream random
+// playouts of az_mcts_search_rollout run on the host, where the reference's mt19937 lives).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -31,7 +33,7 @@ struct Connect4Dev {
     static constexpr bool AUX_PLUS_ONE = true, AUX_NEGATE = false;   // Connect4.h:34-35
     static constexpr int BPC = 7;
 
-    __device__ static bool four(uint64_t b)               // Connect4.h:182-203
+    __host__ __device__ static bool four(uint64_t b)               // Connect4.h:182-203
     {
         uint64_t t;
         t = b & (b >> 1); if (t & (t >> 2)) return true;
@@ -41,13 +43,13 @@ struct Connect4Dev {
         return false;
     }
     // last mover from piece parity, as import_board derives it (Connect4.h:124-128)
-    __device__ static int root_aux(uint64_t bb0, uint64_t bb1)
+    __host__ __device__ static int root_aux(uint64_t bb0, uint64_t bb1)
     {
-        const int pieces = __popcll(bb0 | bb1);
+        const int pieces = __builtin_popcountll(bb0 | bb1);
         return pieces == 0 ? -1 : ((pieces & 1) ? 0 : 1);
     }
-    __device__ static void start(GameState &s) { s.bb0 = 0; s.bb1 = 0; s.turn = 1; s.aux = -1; }
-    __device__ static void import_cells(const int8_t *b, GameState &s)   // Connect4.h:87-129
+    __host__ __device__ static void start(GameState &s) { s.bb0 = 0; s.bb1 = 0; s.turn = 1; s.aux = -1; }
+    __host__ __device__ static void import_cells(const int8_t *b, GameState &s)   // Connect4.h:87-129
     {
         uint64_t bb0 = 0, bb1 = 0;
         for (int c = 0; c < COLS; ++c) {
@@ -61,7 +63,7 @@ struct Connect4Dev {
         }
         s.bb0 = bb0; s.bb1 = bb1; s.aux = root_aux(bb0, bb1);
     }
-    __device__ static void step(GameState &s, int action)  // Connect4.h:159-172
+    __host__ __device__ static void step(GameState &s, int action)  // Connect4.h:159-172
     {
         const uint64_t colmask = 0x7Full << (BPC * action);
         const uint64_t mv = (((s.bb0 | s.bb1) & colmask) + (1ull << (BPC * action))) & colmask;
@@ -71,24 +73,24 @@ struct Connect4Dev {
         s.turn = -s.turn;
     }
     // -1 not terminal, 0 draw, 1 P1 wins, 2 P2 wins (check_winner then is_full, MCTS.h:279-288)
-    __device__ static int result(const GameState &s)
+    __host__ __device__ static int result(const GameState &s)
     {
         if (s.aux >= 0 && four(s.aux == 0 ? s.bb0 : s.bb1)) return s.aux == 0 ? 1 : 2;
-        if (__popcll(s.bb0 | s.bb1) == CELLS) return 0;
+        if (__builtin_popcountll(s.bb0 | s.bb1) == CELLS) return 0;
         return -1;
     }
-    __device__ static bool col_open(const GameState &s, int c)
+    __host__ __device__ static bool col_open(const GameState &s, int c)
     {
         return !(((s.bb0 | s.bb1) >> (c * BPC + ROWS - 1)) & 1ull);
     }
-    __device__ static int num_valid(const GameState &s)    // Connect4.h:209-218
+    __host__ __device__ static int num_valid(const GameState &s)    // Connect4.h:209-218
     {
         int n = 0;
 #pragma unroll
         for (int c = 0; c < COLS; ++c) n += col_open(s, c) ? 1 : 0;
         return n;
     }
-    __device__ static int nth_valid(const GameState &s, int n)
+    __host__ __device__ static int nth_valid(const GameState &s, int n)
     {
         int k = 0, a = -1;
 #pragma unroll
@@ -96,7 +98,7 @@ struct Connect4Dev {
             if (col_open(s, c)) { if (k == n) a = c; ++k; }
         return a;
     }
-    __device__ static float aux_utility(float child_m, float parent_m, float child_q, const SearchParams &p)
+    __host__ __device__ static float aux_utility(float child_m, float parent_m, float child_q, const SearchParams &p)
     {                                                      // Connect4.h:231-239
         if (!(p.mlh_slope > 0.0f)) return 0.0f;
         const float v = p.mlh_slope * (child_m - parent_m);
@@ -104,12 +106,12 @@ struct Connect4Dev {
         const float cl = (v < lo) ? lo : ((hi < v) ? hi : v);
         return cl * child_q;
     }
-    __device__ static float terminal_aux(const GameState &, const SearchParams &) { return 0.0f; }
-    __device__ static int sym_of_choice(int choice) { return choice; }
+    __host__ __device__ static float terminal_aux(const GameState &, const SearchParams &) { return 0.0f; }
+    __host__ __device__ static int sym_of_choice(int choice) { return choice; }
     // policy entry (evaluator frame) that belongs to `action` of the unsymmetrised leaf
-    __device__ static int policy_index(int sym, int action) { return sym ? (COLS - 1 - action) : action; }
+    __host__ __device__ static int policy_index(int sym, int action) { return sym ? (COLS - 1 - action) : action; }
     // stone at display cell (row-major) of the symmetrised board (Connect4.h:249-280)
-    __device__ static int cell_value(const GameState &s, int sym, int cell)
+    __host__ __device__ static int cell_value(const GameState &s, int sym, int cell)
     {
         const int r = cell / COLS, c = cell - r * COLS;
         const int cs = sym ? (COLS - 1 - c) : c;
@@ -117,7 +119,7 @@ struct Connect4Dev {
         return ((s.bb0 >> bit) & 1ull) ? 1 : (((s.bb1 >> bit) & 1ull) ? -1 : 0);
     }
     // is action index `a` of the symmetrised leaf legal
-    __device__ static bool valid_in_frame(const GameState &s, int sym, int a)
+    __host__ __device__ static bool valid_in_frame(const GameState &s, int sym, int a)
     {
         return col_open(s, sym ? (COLS - 1 - a) : a);
     }
@@ -135,7 +137,7 @@ struct OthelloDev {
     static constexpr uint64_t NOT_A = 0xFEFEFEFEFEFEFEFEull, NOT_H = 0x7F7F7F7F7F7F7F7Full;
 
     template <int D>
-    __device__ static uint64_t shift(uint64_t b)           // Othello.h:133-148
+    __host__ __device__ static uint64_t shift(uint64_t b)           // Othello.h:133-148
     {
         if (D == 0) return b >> 8;
         if (D == 1) return (b >> 7) & NOT_A;
@@ -147,14 +149,14 @@ struct OthelloDev {
         return (b >> 9) & NOT_H;
     }
     template <int D>
-    __device__ static uint64_t valid_dir(uint64_t own, uint64_t opp, uint64_t empty)
+    __host__ __device__ static uint64_t valid_dir(uint64_t own, uint64_t opp, uint64_t empty)
     {
         uint64_t c = shift<D>(own) & opp;
 #pragma unroll
         for (int i = 0; i < 5; ++i) c |= shift<D>(c) & opp;
         return shift<D>(c) & empty;
     }
-    __device__ static uint64_t valid_positions(const GameState &s)   // Othello.h:155-171
+    __host__ __device__ static uint64_t valid_positions(const GameState &s)   // Othello.h:155-171
     {
         const uint64_t own = (s.turn == 1) ? s.bb0 : s.bb1, opp = (s.turn == 1) ? s.bb1 : s.bb0;
         const uint64_t empty = ~(own | opp);
@@ -163,7 +165,7 @@ struct OthelloDev {
                valid_dir<6>(own, opp, empty) | valid_dir<7>(own, opp, empty);
     }
     template <int D>
-    __device__ static uint64_t flips_dir(uint64_t placed, uint64_t own, uint64_t opp)
+    __host__ __device__ static uint64_t flips_dir(uint64_t placed, uint64_t own, uint64_t opp)
     {
         uint64_t cand = 0, sq = shift<D>(placed);
 #pragma unroll
@@ -174,12 +176,12 @@ struct OthelloDev {
         }
         return (sq & own) ? cand : 0ull;
     }
-    __device__ static int root_aux(uint64_t, uint64_t) { return 0; }   // import forgets passes (Othello.h:108-110)
-    __device__ static void start(GameState &s)            // Othello.h:62-75
+    __host__ __device__ static int root_aux(uint64_t, uint64_t) { return 0; }   // import forgets passes (Othello.h:108-110)
+    __host__ __device__ static void start(GameState &s)            // Othello.h:62-75
     {
         s.bb0 = (1ull << 28) | (1ull << 35); s.bb1 = (1ull << 27) | (1ull << 36); s.turn = 1; s.aux = 0;
     }
-    __device__ static void import_cells(const int8_t *b, GameState &s)  // Othello.h:87-111
+    __host__ __device__ static void import_cells(const int8_t *b, GameState &s)  // Othello.h:87-111
     {
         uint64_t bb0 = 0, bb1 = 0;
         for (int i = 0; i < CELLS; ++i) {
@@ -188,7 +190,7 @@ struct OthelloDev {
         }
         s.bb0 = bb0; s.bb1 = bb1; s.aux = 0;
     }
-    __device__ static void step(GameState &s, int action)  // Othello.h:206-235
+    __host__ __device__ static void step(GameState &s, int action)  // Othello.h:206-235
     {
         if (action == PASS) { s.aux += 1; s.turn = -s.turn; return; }
         const bool p1 = s.turn == 1;
@@ -203,42 +205,42 @@ struct OthelloDev {
         s.aux = 0;
         s.turn = -s.turn;
     }
-    __device__ static bool over(const GameState &s) { return __popcll(s.bb0 | s.bb1) == 64 || s.aux >= 2; }
-    __device__ static int result(const GameState &s)       // Othello.h:241-258, is_full == is_game_over
+    __host__ __device__ static bool over(const GameState &s) { return __builtin_popcountll(s.bb0 | s.bb1) == 64 || s.aux >= 2; }
+    __host__ __device__ static int result(const GameState &s)       // Othello.h:241-258, is_full == is_game_over
     {
         if (!over(s)) return -1;
-        const int a = __popcll(s.bb0), b = __popcll(s.bb1);
+        const int a = __builtin_popcountll(s.bb0), b = __builtin_popcountll(s.bb1);
         return a > b ? 1 : (b > a ? 2 : 0);
     }
-    __device__ static int num_valid(const GameState &s)    // Othello.h:283-294
+    __host__ __device__ static int num_valid(const GameState &s)    // Othello.h:283-294
     {
         if (over(s)) return 0;
         const uint64_t v = valid_positions(s);
-        return v ? __popcll(v) : 1;
+        return v ? __builtin_popcountll(v) : 1;
     }
-    __device__ static int nth_valid(const GameState &s, int n)
+    __host__ __device__ static int nth_valid(const GameState &s, int n)
     {
         if (over(s)) return -1;
         uint64_t v = valid_positions(s);
         if (v == 0) return n == 0 ? PASS : -1;
-        if (n >= static_cast<int>(__popcll(v))) return -1;
+        if (n >= static_cast<int>(__builtin_popcountll(v))) return -1;
         for (int i = 0; i < n; ++i) v &= v - 1;
-        return __ffsll(static_cast<unsigned long long>(v)) - 1;
+        return __builtin_ffsll(static_cast<long long>(v)) - 1;
     }
     // MCTS.h:197-198 negates the child's mean before Othello.h:268-274 weighs it
-    __device__ static float aux_utility(float child_m, float, float, const SearchParams &p)
+    __host__ __device__ static float aux_utility(float child_m, float, float, const SearchParams &p)
     {
         if (!(p.score_utility_factor > 0.0f)) return 0.0f;
         return p.score_utility_factor * (-child_m);
     }
     // Othello.h:260-266 through the host-tabulated atan (index = diff*turn + 64)
-    __device__ static float terminal_aux(const GameState &s, const SearchParams &p)
+    __host__ __device__ static float terminal_aux(const GameState &s, const SearchParams &p)
     {
-        const int diff = __popcll(s.bb0) - __popcll(s.bb1);
+        const int diff = __builtin_popcountll(s.bb0) - __builtin_popcountll(s.bb1);
         return p.term_aux_tab[diff * s.turn + 64];
     }
-    __device__ static int sym_of_choice(int choice) { return choice == 0 ? 0 : (choice == 1 ? 2 : (choice == 2 ? 6 : 7)); }
-    __device__ static int transform_sq(int sym, int sq)    // Othello.h:312-326
+    __host__ __device__ static int sym_of_choice(int choice) { return choice == 0 ? 0 : (choice == 1 ? 2 : (choice == 2 ? 6 : 7)); }
+    __host__ __device__ static int transform_sq(int sym, int sq)    // Othello.h:312-326
     {
         const int r = sq >> 3, c = sq & 7;
         int nr = r, nc = c;
@@ -254,20 +256,20 @@ struct OthelloDev {
         }
         return nr * 8 + nc;
     }
-    __device__ static int inverse_sym(int sym) { return sym == 1 ? 3 : (sym == 3 ? 1 : sym); }
+    __host__ __device__ static int inverse_sym(int sym) { return sym == 1 ? 3 : (sym == 3 ? 1 : sym); }
     // inverse_symmetry_policy (Othello.h:373-387): unsym[T_inv(i)] = policy[i]  =>  the entry
     // for `action` is policy[T_sym(action)]; pass is not moved
-    __device__ static int policy_index(int sym, int action)
+    __host__ __device__ static int policy_index(int sym, int action)
     {
         return (action == PASS || sym == 0) ? action : transform_sq(sym, action);
     }
     // apply_symmetry moves stone i to T_sym(i): the stone shown at cell j was at T_inv(j)
-    __device__ static int cell_value(const GameState &s, int sym, int cell)
+    __host__ __device__ static int cell_value(const GameState &s, int sym, int cell)
     {
         const int src = sym == 0 ? cell : transform_sq(inverse_sym(sym), cell);
         return ((s.bb0 >> src) & 1ull) ? 1 : (((s.bb1 >> src) & 1ull) ? -1 : 0);
     }
-    __device__ static bool valid_in_frame(const GameState &s, int sym, int a)
+    __host__ __device__ static bool valid_in_frame(const GameState &s, int sym, int a)
     {
         if (over(s)) return false;
         const uint64_t v = valid_positions(s);

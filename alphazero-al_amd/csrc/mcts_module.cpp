@@ -61,11 +61,14 @@ void register_game(py::module_ &m, const char *suffix)
     const std::string cls = std::string("BatchedMCTS_") + suffix;
     // IEvaluator_<G> / RolloutEvaluator_<G> (mcts_bindings.cpp:41-48): the rollout evaluator is
     // a tag object here - the random playouts run inside the engine.
-    struct IEval {};
+    // `device_rng` (an addition): False = playout moves from the reference's random stream on the host
+    // (bit-exact, az_mcts_search_rollout), True = playouts on the device (az_mcts_search_rollout_dev).
+    struct IEval { bool device_rng = false; };
     struct RolloutEval : IEval {};
     py::class_<IEval>(m, (std::string("IEvaluator_") + suffix).c_str());
     py::class_<RolloutEval, IEval>(m, (std::string("RolloutEvaluator_") + suffix).c_str())
-        .def(py::init<>());
+        .def(py::init<>())
+        .def_readwrite("device_rng", &RolloutEval::device_rng);
 
     py::class_<BM>(m, cls.c_str())
         .def(py::init<int>(), py::arg("n_envs"))
@@ -223,7 +226,7 @@ void register_game(py::module_ &m, const char *suffix)
              py::arg("p2w_vals"), py::arg("moves_left"), py::arg("is_term"), py::arg("sym_ids"),
              "VL Backprop: remove VL then backprop N*K results")
         .def("search",
-             [](BM &self, IEval &, carray<int8_t> input_boards, carray<int> turns, int n_playout) {
+             [](BM &self, IEval &ev, carray<int8_t> input_boards, carray<int> turns, int n_playout) {
                  auto bi = input_boards.request();
                  const py::ssize_t n = bi.ndim ? bi.shape[0] : 0;
                  if (n != self.n())
@@ -235,7 +238,8 @@ void register_game(py::module_ &m, const char *suffix)
                      auto *pin = static_cast<const int8_t *>(bi.ptr);
                      auto *ptn = turns.data();
                      py::gil_scoped_release rel;
-                     rc = az_mcts_search_rollout(self.h(), pin, ptn, n, n_playout);
+                     rc = ev.device_rng ? az_mcts_search_rollout_dev(self.h(), pin, ptn, n, n_playout)
+                                        : az_mcts_search_rollout(self.h(), pin, ptn, n, n_playout);
                  }
                  check(rc);
              },

@@ -107,9 +107,16 @@ int az_mcts_backprop_batch_vl(az_mcts *m, int K, const float *policy, const floa
                               const float *p1w, const float *p2w, const float *moves_left,
                               const uint8_t *is_term, const int32_t *sym_ids, int64_t total);
 /* search(RolloutEvaluator, ...), mcts_bindings.cpp:313-337 / BatchedMCTS.h:339-407 with
- * RolloutEvaluator.h:23-48: whole playout loop on the device, random playouts as evaluator */
+ * RolloutEvaluator.h:23-48, in the reference's random stream like every host entry point: playout
+ * moves (one uniform_int per move, leaves in env order) and root-noise rows come from the host
+ * mt19937 as the reference with OMP_NUM_THREADS=1 consumes them - bit-exact against it (fixture G9);
+ * selection, expansion and backup run on the device, one host round trip per playout. */
 int az_mcts_search_rollout(az_mcts *m, const int8_t *boards, const int32_t *turns, int64_t n,
                            int n_playout);
+/* The same search with the random playouts on the device as well (moves and noise from the device
+ * generator: same distribution, another stream; no host round trip inside the loop). */
+int az_mcts_search_rollout_dev(az_mcts *m, const int8_t *boards, const int32_t *turns, int64_t n,
+                               int n_playout);
 /* get_all_counts, mcts_bindings.cpp:342 / BatchedMCTS.h:413-427: out[n_envs*A] */
 int az_mcts_get_all_counts(az_mcts *m, int32_t *out);
 /* get_all_root_stats, mcts_bindings.cpp:348-356 / MCTS.h:637-673: out[n_envs*(6+8A)] */

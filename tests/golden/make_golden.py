@@ -207,6 +207,25 @@ def gen_rollout():
     w.rollout_playout(boards, turns)
     save("g9_rollout", boards=boards, turns=turns, counts=w.get_visits_count().astype(np.int32),
          stats=w.mcts.get_all_root_stats())
+    # root noise drawn between the playout moves (alpha > 0), two searches on the same trees, and Othello
+    out = {}
+    rng = np.random.default_rng(78)
+    boards, turns = S.random_openings(rng, 24, 20)
+    w = BatchedMCTS(24, c_init=4, c_base=500, alpha=0.3, n_playout=90, game_name="Connect4",
+                    noise_epsilon=0.25, fpu_reduction=0.2, use_symmetry=False)
+    w.seed(11)
+    w.rollout_playout(boards, turns)
+    out.update(c4_boards=boards, c4_turns=turns, c4_counts1=w.get_visits_count().astype(np.int32),
+               c4_stats1=w.mcts.get_all_root_stats())
+    w.rollout_playout(boards, turns)
+    out.update(c4_counts2=w.get_visits_count().astype(np.int32), c4_stats2=w.mcts.get_all_root_stats())
+    b, t = S.ot_openings(rng, 16, 44, 2)
+    w = BatchedMCTS(16, c_init=4, c_base=300, alpha=0.3, n_playout=60, game_name="Othello",
+                    noise_epsilon=0.25, fpu_reduction=0.2, use_symmetry=False, score_utility_factor=0.15, score_scale=8.0)
+    w.seed(5)
+    w.rollout_playout(b, t)
+    out.update(ot_boards=b, ot_turns=t, ot_counts=w.get_visits_count().astype(np.int32), ot_stats=w.mcts.get_all_root_stats())
+    save("g9_rollout_more", **out)
 
 
 # ------------------------------------------------------------------ G7 network

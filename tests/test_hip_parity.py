@@ -196,8 +196,32 @@ def test_raw_c_abi_via_ctypes(mcts_cpp):
     L.az_mcts_destroy(h)
 
 
+def test_g9_rollout_search_bit_exact(mcts_cpp):
+    """a27: `search(RolloutEvaluator_<G>(), ...)` on the HIP engine against the reference's own
+    outputs - fixture G9 (120 playouts, 12 positions) and g9_rollout_more (Dirichlet noise drawn
+    between the playout moves, a second search on the same trees, Othello with passes): playout
+    moves and noise come from the reference's mt19937 stream in env order
+    (RolloutEvaluator.h:44-46, MCTS.h:352-358).  Visit counts and root statistics bit for bit."""
+    from test_oracle_golden import check_rollout_more
+    g = load("g9_rollout")
+    m = mcts_cpp.BatchedMCTS_Connect4(12)
+    S.apply_cfg(m, dict(c_init=4.0, c_base=500.0, dirichlet_alpha=0.0, noise_epsilon=0.0,
+                        fpu_reduction=0.0, use_symmetry=False, mlh_slope=0.0, mlh_cap=0.2, value_decay=1.0))
+    m.set_seed(3)
+    ev = mcts_cpp.RolloutEvaluator_Connect4()
+    assert ev.device_rng is False
+    m.search(ev, g["boards"], g["turns"], 120)
+    assert np.array_equal(S.counts_of(m, 12), g["counts"])
+    assert np.array_equal(bits(np.array(m.get_all_root_stats())), bits(g["stats"]))
+
+    def rollout(m, b, t, n):
+        ev = (mcts_cpp.RolloutEvaluator_Othello if m.action_size == 65 else mcts_cpp.RolloutEvaluator_Connect4)()
+        m.search(ev, b, t, n)
+    check_rollout_more(mcts_cpp.BatchedMCTS_Connect4, mcts_cpp.BatchedMCTS_Othello, rollout)
+
+
 def test_rollout_search_on_device(mcts_cpp):
-    """a27: BatchedMCTS::search with RolloutEvaluator.  Playout moves come from the device
+    """a27 with `device_rng`: the playouts run on the device as well, moves from the device
     generator, so the comparison with the (bit-exact) oracle is statistical; what is exact:
     the simulation budget, and forced lines."""
     from src import MCTS_cpp
@@ -208,6 +232,7 @@ def test_rollout_search_on_device(mcts_cpp):
     w = MCTS_cpp.BatchedMCTS(256, c_init=4, c_base=500, alpha=0, n_playout=300, noise_epsilon=0.0,
                              fpu_reduction=0.0, use_symmetry=False)               # player.py:84-88
     w.seed(3)
+    w._get_rollout_evaluator().device_rng = True
     w.rollout_playout(boards, turns)
     c = w.get_visits_count()
     st = w.get_root_stats()

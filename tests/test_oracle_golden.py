@@ -178,6 +178,36 @@ def test_g9_rollout_search():
     assert np.array_equal(bits(m.get_all_root_stats()), bits(g["stats"]))
 
 
+ROLLOUT_C4 = dict(c_init=4.0, c_base=500.0, dirichlet_alpha=0.3, noise_epsilon=0.25, fpu_reduction=0.2,
+                  use_symmetry=False, mlh_slope=0.0, mlh_cap=0.2, value_decay=1.0)
+ROLLOUT_OT = dict(c_init=4.0, c_base=300.0, dirichlet_alpha=0.3, noise_epsilon=0.25, fpu_reduction=0.2,
+                  use_symmetry=False, mlh_slope=0.0, mlh_cap=0.2, value_decay=1.0, score_utility_factor=0.15,
+                  score_scale=8.0)
+
+
+def check_rollout_more(make_c4, make_ot, rollout):
+    """g9_rollout_more: root noise drawn between the playout moves, a second search on the same
+    trees, and Othello rollouts (passes, score utility).  rollout(m, boards, turns, n)."""
+    g = load("g9_rollout_more")
+    m = make_c4(24)
+    S.apply_cfg(m, ROLLOUT_C4)
+    m.set_seed(11)
+    for tag in ("1", "2"):
+        rollout(m, g["c4_boards"], g["c4_turns"], 90)
+        assert np.array_equal(S.counts_of(m, 24), g["c4_counts" + tag])
+        assert np.array_equal(bits(np.array(m.get_all_root_stats())), bits(g["c4_stats" + tag]))
+    m = make_ot(16)
+    S.apply_cfg(m, ROLLOUT_OT)
+    m.set_seed(5)
+    rollout(m, g["ot_boards"], g["ot_turns"], 60)
+    assert np.array_equal(S.counts_of(m, 16, 65), g["ot_counts"])
+    assert np.array_equal(bits(np.array(m.get_all_root_stats())), bits(g["ot_stats"]))
+
+
+def test_g9_rollout_more():
+    check_rollout_more(O.BatchedMCTS_Connect4, O.BatchedMCTS_Othello, lambda m, b, t, n: m.search_rollout(b, t, n))
+
+
 # ------------------------------------------------------------------ Othello (a32, config 4)
 def check_othello(name, make):
     g = load(name)
