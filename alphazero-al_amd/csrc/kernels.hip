@@ -544,6 +544,262 @@ __global__ void __launch_bounds__(WAVE) k_select_staggered(TreeArena ar, RootSta
     wave_add_counter(counters, CNT_SIMS, (live && sub == 0) ? static_cast<unsigned>(K) : 0u);
 }
 
+// ------------------------------------------------------------------ selection, Connect4-shaped groups of 8 lanes
+//
+// k_select run by ONE wavefront per SIMD issues every instruction - vector or scalar - at 4 cycles, so
+// a level costs (instructions x 4) cycles plus its waits, and a launch ends when the wavefront with the
+// deepest trees is done.  k_select's level body is ~400 instructions and its leaf path another ~430;
+// the eight trees of a wavefront are out of step, so nearly every trip through its loop pays BOTH.
+// This kernel computes the same search (bit-identical: tests) with the instruction stream cut down:
+//   * a trip = one level, then - only for groups that just arrived at a leaf - a short emit; no trips
+//     spent on leaves alone (levels instead of levels + K trips per tree);
+//   * cross-lane traffic inside a group is DPP on the vector ALU (quad_perm / row_half_mirror compose
+//     every 8-lane exchange): the ordered 7-term prior sum and the (score, lowest index) arg-max no
+//     longer take five dependent trips through the LDS crossbar; the arg-max runs on an
+//     order-preserving integer key and ends in one ballot;
+//   * what the winner's lane holds is fetched in ONE batch of seven independent ds_bpermute; the new
+//     node's flags are then computed by every lane alike instead of being computed by one and re-sent;
+//   * predicated single-lane stores (a branch each) are gathered into one block per level and one per
+//     leaf; the first 16 path entries ride in two registers per lane (lane j keeps depths j, j+8) and
+//     leave with two unconditional stores per leaf (entries past the path's end are ignored downstream);
+//   * while a level's arithmetic runs, every lane touches the first, middle and last record of ITS
+//     child's own child block, so that the block picked a few hundred cycles later is in the cache
+//     hierarchy already (the loads are issued from inline assembly: results unused).
+constexpr int DPP_QP0 = 0x00, DPP_QP1 = 0x55, DPP_QP2 = 0xAA, DPP_QP3 = 0xFF;     // quad_perm broadcasts of lane 0..3
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_QREV = 0x1B;                  // quad_perm [1,0,3,2] [2,3,0,1] [3,2,1,0]
+constexpr int DPP_HALF_MIRROR = 0x141;                                            // lane i <- lane 7 - i in each 8
+
+template <int CTRL, int BANK_MASK = 0xf>
+__device__ __forceinline__ float dpp_f(float old, float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(x), CTRL, 0xf, BANK_MASK, false));
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u(uint32_t x)
+{
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(x), static_cast<int>(x), CTRL, 0xf, 0xf, false));
+}
+
+// ((((((0 + t0) + t1) + t2) + t3) + t4) + t5) + t6 of the group's lanes 0..6, in every lane of the group:
+// the order of `for (i < 7) sum += shfl(t, i)`, i.e. of the reference's loop over edges.  Lanes 0-3 add
+// their quad's four terms, the running sum crosses to lanes 4-7 mirrored, they add theirs, and the total
+// crosses back into the banks of lanes 0-3.
+__device__ __forceinline__ float group8_ordered_sum7(float t)
+{
+    float a = 0.0f + dpp_f<DPP_QP0>(t, t);
+    a = a + dpp_f<DPP_QP1>(t, t);
+    a = a + dpp_f<DPP_QP2>(t, t);
+    a = a + dpp_f<DPP_QP3>(t, t);
+    const float x = dpp_f<DPP_HALF_MIRROR>(a, a);
+    float s = x + dpp_f<DPP_QP0>(t, t);
+    s = s + dpp_f<DPP_QP1>(t, t);
+    s = s + dpp_f<DPP_QP2>(t, t);
+    return dpp_f<DPP_HALF_MIRROR, 0x5>(s, s);          // banks 0 and 2 (lanes 0-3 of each group) take lanes 7-4's total
+}
+
+// Lane of the group's largest score, the lowest one on ties; -1 if no lane is `valid` or every valid
+// score is -inf (MCTS.h:172,226-231: strict '>' over ascending edges, from -inf).
+__device__ __forceinline__ int group8_argmax(float score, bool valid, int lane)
+{
+    const float s = valid ? score + 0.0f : -INFINITY;  // -0 -> +0: the two compare equal in the reference
+    const uint32_t b = __float_as_uint(s);
+    const uint32_t key = b ^ (static_cast<uint32_t>(static_cast<int32_t>(b) >> 31) | 0x80000000u);   // order-preserving
+    uint32_t m = max(key, dpp_u<DPP_XOR1>(key));
+    m = max(m, dpp_u<DPP_XOR2>(m));
+    m = max(m, dpp_u<DPP_QREV>(dpp_u<DPP_HALF_MIRROR>(m)));                                         // lane ^ 4
+    const unsigned long long bal = __ballot(key == m && m != 0x007FFFFFu);                          // 0x007FFFFF = key(-inf)
+    const uint32_t g = static_cast<uint32_t>(bal >> (lane & 56)) & 0xffu;
+    return g ? __ffs(g) - 1 : -1;
+}
+
+__device__ __forceinline__ void touch_line(const void *p, int &sink)
+{
+    asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(p));
+}
+
+template <bool VL>
+__global__ void __launch_bounds__(WAVE) k_select8(TreeArena ar, RootState rs, LeafBuf lf, SearchParams p, int K,
+                                                  int tpw, unsigned long long *counters, uint64_t *bump, long long *zero,
+                                                  int prefetch)
+{
+    using G = Connect4Dev;
+    constexpr int L = 8;
+    const int lane = threadIdx.x;
+    if (bump != nullptr && blockIdx.x == 0 && lane == 0) *bump += 1;      // see k_select
+    if (zero != nullptr && blockIdx.x == 0 && lane == 0) *zero = 0;
+    const int sub = lane % L;
+    const int grp = lane / L;
+    const int tree = blockIdx.x * tpw + grp;
+    const bool live = grp < tpw && tree < ar.B;
+    const int t = live ? tree : 0;
+    const float ne = p.noise_eps_tree != nullptr ? p.noise_eps_tree[t] : p.noise_eps;
+    const bool root_mix = ne > 0.0f;
+
+    HotRec *hot = ar.hot + static_cast<size_t>(t) * ar.S;
+    const ColdRec *cold = ar.cold + static_cast<size_t>(t) * ar.S;
+    const int root = ar.root[t];
+    HotRec rootrec = hot[root];
+    int root_infl = rootrec.n_inflight;
+    GameState rstate;
+    rstate.bb0 = rs.bb0[t]; rstate.bb1 = rs.bb1[t]; rstate.turn = rs.turn[t]; rstate.aux = rs.aux[t];
+
+    int k = 0;
+    bool done = !live;
+    int cur = root, cur_lane = 0, depth = 0;
+    HotRec R = rootrec;
+    GameState st = rstate;
+    size_t flat = static_cast<size_t>(t) * K;
+    int path0 = root, path1 = 0;                      // this lane's path entries: depths sub and sub + 8
+    unsigned n_levels = 0, n_terminal = 0;
+    int pf0 = 0, pf1 = 0, pf2 = 0;
+
+    auto is_leaf = [](uint32_t meta) {                // MCTS.h:250-258
+        return !(meta & META_EXPANDED) || (meta & META_TERMINAL) || (meta & META_NEDGE_MASK) == 0;
+    };
+    // MCTS.h:291-321 / 512-544: what a finished descent leaves behind, then the next descent starts at the root
+    auto emit = [&]() {
+        uint32_t lm = R.meta;
+        bool term = (lm & META_TERMINAL) != 0;
+        int code = static_cast<int>((lm & META_RESULT_MASK) >> META_RESULT_SHIFT);
+        if (depth == 0 && !term) {                    // a node entered by a move carries its result already (MCTS.h:279-288)
+            const int res = G::result(st);
+            if (res >= 0) {
+                term = true; code = res;
+                lm = (lm & ~META_RESULT_MASK) | META_TERMINAL | (static_cast<uint32_t>(res) << META_RESULT_SHIFT);
+                if (sub == cur_lane) hot[cur].meta = lm;
+                rootrec.meta = lm;
+            }
+        }
+        if (term) ++n_terminal;
+        uint8_t fl = static_cast<uint8_t>((term ? LEAF_TERMINAL : 0) | (code << LEAF_RESULT_SHIFT));
+        if (VL && depth > 0) fl |= LEAF_VL_APPLIED;
+        if (depth == 0 && !(lm & META_EXPANDED)) fl |= LEAF_ROOT_UNEXPANDED;
+        if (lm & META_EXPANDED) fl |= LEAF_EXPANDED;
+        constexpr uint64_t TOP = 0x0000810204081020ull;               // the top cell of every column
+        const int nv = term ? 0 : 7 - static_cast<int>(__builtin_popcountll((st.bb0 | st.bb1) & TOP));
+        int32_t *path = lf.path + flat * G::MAX_PATH;
+        path[sub] = path0;                                             // entries past depth are ignored downstream
+        path[sub + 8] = path1;
+        if (sub == 0) {
+            lf.slot[flat] = cur; lf.bb0[flat] = st.bb0; lf.bb1[flat] = st.bb1; lf.turn[flat] = st.turn;
+            lf.flags[flat] = fl; lf.path_len[flat] = depth + 1; lf.aux[flat] = st.aux;
+            lf.nvalid[flat] = static_cast<uint8_t>(nv);
+        }
+        ++k;
+        if (k == K) {
+            done = true;
+        } else {
+            ++flat;
+            cur = root; cur_lane = 0; depth = 0;
+            R = rootrec; R.n_inflight = root_infl;
+            st = rstate;
+            path0 = root;                                              // depth 0 in lane 0; the others are overwritten on the way
+        }
+    };
+
+    while (!done && is_leaf(R.meta)) emit();          // a root that is a leaf ends all K descents where they start
+
+    for (;;) {
+        if (!done) {
+            // ---- one level from the inner node R (MCTS.h:140-234 across the lanes)
+            const uint32_t meta = R.meta;
+            const int E = static_cast<int>((meta & META_NEDGE_MASK) >> META_NEDGE_SHIFT);
+            const bool has = sub < E;
+            const bool is_root = cur == root;
+            HotRec c = hot[R.child_off + (has ? sub : 0)];
+            float noise = 0.0f;
+            if (is_root && root_mix && has) noise = cold[R.child_off + sub].noise;
+            if (!has) { c.meta = 0u; c.prior = 0.0f; c.child_off = -1; }
+            const bool exists = (c.meta & META_EXISTS) != 0;
+            asm volatile("" :: "v"(pf0), "v"(pf1), "v"(pf2), "v"(c.meta));     // last level's touches are older than this load
+            if (prefetch) {
+                const int cE = static_cast<int>((c.meta & META_NEDGE_MASK) >> META_NEDGE_SHIFT);
+                if ((c.meta & META_EXPANDED) && cE > 0) {
+                    const HotRec *blk = hot + c.child_off;
+                    touch_line(blk, pf0);
+                    touch_line(blk + (cE >> 1), pf1);
+                    touch_line(blk + (cE - 1), pf2);
+                }
+            }
+            const bool real = exists && c.n_visits > 0;
+
+            const float pq = mean_q(R.n_visits, R.w_p1, R.w_p2, (meta & META_TURN_P1) != 0);
+            const float seen = group8_ordered_sum7(real ? c.prior : 0.0f);
+            const float scale = (1.0f + pq) / 2.0f;
+            const float eff = p.fpu_reduction * scale;
+            float fpu = fmaf(-eff, sqrtf(seen), pq);
+            fpu = (-1.0f < fpu) ? fpu : -1.0f;
+
+            const int pn_i = R.n_visits + R.n_inflight;
+            const float parent_n = static_cast<float>(pn_i);
+            const float parent_m = mean_m(R.n_visits, R.m_sum);
+            const float c_puct = (pn_i >= 0 && pn_i < p.tab_n)
+                ? p.cpuct_tab[pn_i]
+                : p.c_init + logf((parent_n + p.c_base + 1.0f) / p.c_base);
+            float eff_prior = c.prior;
+            if (is_root && root_mix) eff_prior = fmaf(c.prior, 1.0f - ne, ne * noise);
+
+            float q = fpu, child_q = 0.0f, child_m = 0.0f;
+            int child_total = (exists && c.n_inflight > 0) ? c.n_inflight : 0;
+            if (real) {
+                child_total = c.n_visits + c.n_inflight;
+                child_q = mean_q(c.n_visits, c.w_p1, c.w_p2, (c.meta & META_TURN_P1) != 0);
+                child_m = mean_m(c.n_visits, c.m_sum);
+                q = -child_q;
+            }
+            const float u = c_puct * eff_prior * sqrtf(parent_n) / (1.0f + static_cast<float>(child_total));
+            const float m_util = real ? G::aux_utility(child_m, parent_m, child_q, p) : 0.0f;
+            const float score = q + u + m_util;
+            const int best = group8_argmax(score, has && score == score, lane);
+
+            if (best >= 0) {
+                ++n_levels;
+                if (VL && depth == 0) root_infl += p.vl_count;                 // MCTS.h:470-475
+                // the winner's record, one batch of independent exchanges
+                const int src = (lane & 56) + best;
+                const uint32_t bmeta = static_cast<uint32_t>(__shfl(static_cast<int>(c.meta), src));
+                const int b_off = __shfl(c.child_off, src);
+                const int b_n = __shfl(c.n_visits, src);
+                const int b_infl = __shfl(c.n_inflight, src);
+                const float b_w1 = __shfl(c.w_p1, src);
+                const float b_w2 = __shfl(c.w_p2, src);
+                const float b_ms = __shfl(c.m_sum, src);
+                G::step(st, static_cast<int>(bmeta & META_ACTION_MASK));
+                const int res = G::result(st);
+                uint32_t nm = bmeta;
+                if (!(nm & META_EXISTS))                                       // lazy child, MCTS.h:268-275
+                    nm = (nm & ~META_TURN_P1) | META_EXISTS | (st.turn == 1 ? META_TURN_P1 : 0u);
+                if (res >= 0)                                                  // MCTS.h:279-288
+                    nm = (nm & ~META_RESULT_MASK) | META_TERMINAL | (static_cast<uint32_t>(res) << META_RESULT_SHIFT);
+                const int n_infl = VL ? b_infl + p.vl_count : b_infl;          // MCTS.h:492
+                const int child_slot = R.child_off + best;
+                if (sub == best) {
+                    if (VL) hot[child_slot].n_inflight = n_infl;
+                    if (nm != bmeta) hot[child_slot].meta = nm;
+                }
+                R.n_visits = b_n; R.n_inflight = n_infl; R.w_p1 = b_w1; R.w_p2 = b_w2; R.m_sum = b_ms;
+                R.child_off = b_off; R.meta = nm;
+                cur = child_slot;
+                cur_lane = best;
+                ++depth;
+                if (depth < 8) { if (sub == depth) path0 = cur; }
+                else if (depth < 16) { if (sub == depth - 8) path1 = cur; }
+                else if (sub == 0) lf.path[flat * G::MAX_PATH + depth] = cur;
+            }
+            // arrived at a leaf - or no edge can be chosen (all scores NaN / -inf): the node itself is the leaf
+            if (best < 0 || is_leaf(R.meta)) emit();
+        }
+        if (__all(done)) break;
+    }
+    asm volatile("" :: "v"(pf0), "v"(pf1), "v"(pf2));
+
+    if (live && VL && sub == 0 && root_infl != rootrec.n_inflight) hot[root].n_inflight = root_infl;
+
+    wave_add_counter(counters, CNT_LEVELS, sub == 0 ? n_levels : 0u);
+    wave_add_counter(counters, CNT_TERMINAL, sub == 0 ? n_terminal : 0u);
+    wave_add_counter(counters, CNT_SIMS, (live && sub == 0) ? static_cast<unsigned>(K) : 0u);
+}
+
 // ------------------------------------------------------------------ virtual-loss removal
 
 // MCTS.h:561-581: every node of a recorded path (root included) loses vl_count in-flight
@@ -1335,6 +1591,16 @@ void launch_select(int game, TreeArena ar, RootState rs, LeafBuf lf, SearchParam
                    unsigned long long *counters, hipStream_t s, uint64_t *bump_call, int64_t *zero)
 {
     static const bool staggered = getenv("AZ_SELECT_STAGGERED") != nullptr && getenv("AZ_SELECT_STAGGERED")[0] == '1';
+    // AZ_SELECT_VARIANT: 0 = k_select (the first kernel, every game), 1 = k_select8 (Connect4) without the
+    // touches of the grandchildren blocks, 2 (default) = k_select8 with them
+    static const int variant = [] { const char *e = getenv("AZ_SELECT_VARIANT"); return e ? atoi(e) : 2; }();
+    if (game == Connect4Dev::GAME_ID && variant >= 1 && !(vl && staggered)) {
+        const int tpw = trees_per_wave(Connect4Dev::LANES);
+        const dim3 grid(grid_for(ar.B, tpw)), block(WAVE);
+        if (vl) hipLaunchKernelGGL((k_select8<true>), grid, block, 0, s, ar, rs, lf, p, K, tpw, counters, bump_call, reinterpret_cast<long long *>(zero), variant >= 2 ? 1 : 0);
+        else    hipLaunchKernelGGL((k_select8<false>), grid, block, 0, s, ar, rs, lf, p, K, tpw, counters, bump_call, reinterpret_cast<long long *>(zero), variant >= 2 ? 1 : 0);
+        return;
+    }
     if (vl && staggered && K >= 2 && K <= 4 && game == Connect4Dev::GAME_ID) {
         const int tpw = trees_per_wave(Connect4Dev::LANES);
         hipLaunchKernelGGL((k_select_staggered<Connect4Dev, 4>), dim3(grid_for(ar.B, tpw)), dim3(WAVE), 0, s, ar, rs, lf, p, K,
