@@ -800,6 +800,185 @@ __global__ void __launch_bounds__(WAVE) k_select8(TreeArena ar, RootState rs, Le
     wave_add_counter(counters, CNT_SIMS, (live && sub == 0) ? static_cast<unsigned>(K) : 0u);
 }
 
+// The K <= 4 virtual-loss descents of a tree SIDE BY SIDE in one wavefront: descent j lives in its own
+// group of 8 lanes (a tree takes 32 lanes, a wavefront holds two trees) and starts j steps after
+// descent 0.  The argument for running them one level apart is k_select_staggered's: descent j + 1 meets
+// descent j only through what j leaves on a node when it ARRIVES there (in-flight visits, the EXISTS /
+// TERMINAL bits), and j arrives one step before j + 1 reads that node among its parent's children; two
+// descents of a tree are never on the same level in the same step, so they never write the same record
+// in the same step.  Here the descents of a step execute as lanes of the SAME instructions, so a step
+// costs one level's instructions whatever K is, and a tree needs (deepest descent + K - 1) steps instead
+// of the sum of its descents' depths - which is what a launch waits for: its deepest trees.  A store of
+// step s is read by another lane of the same wavefront in step s + 1: vector memory operations of one
+// wavefront reach its CU's L1 in program order (wavefront scope needs no cache action in the AMDGPU
+// memory model); the fences below only keep the compiler from moving them.  Results are bit-identical
+// to k_select / k_select8 (tests).  Four wavefronts per SIMD at 8192 trees.
+__global__ void __launch_bounds__(WAVE) k_select8x4(TreeArena ar, RootState rs, LeafBuf lf, SearchParams p, int K,
+                                                    unsigned long long *counters, uint64_t *bump, long long *zero)
+{
+    using G = Connect4Dev;
+    const int lane = threadIdx.x;
+    if (bump != nullptr && blockIdx.x == 0 && lane == 0) *bump += 1;      // see k_select
+    if (zero != nullptr && blockIdx.x == 0 && lane == 0) *zero = 0;
+    const int sub = lane & 7;
+    const int j = (lane >> 3) & 3;                    // which descent of its tree this group runs
+    const int tree = blockIdx.x * 2 + (lane >> 5);
+    const bool live = tree < ar.B && j < K;
+    const int t = tree < ar.B ? tree : 0;
+    const float ne = p.noise_eps_tree != nullptr ? p.noise_eps_tree[t] : p.noise_eps;
+    const bool root_mix = ne > 0.0f;
+
+    HotRec *hot = ar.hot + static_cast<size_t>(t) * ar.S;
+    const ColdRec *cold = ar.cold + static_cast<size_t>(t) * ar.S;
+    const int root = ar.root[t];
+    const HotRec rootrec = hot[root];
+    GameState st;
+    st.bb0 = rs.bb0[t]; st.bb1 = rs.bb1[t]; st.turn = rs.turn[t]; st.aux = rs.aux[t];
+
+    bool done = !live;
+    bool passed_root = false;                         // this descent left the root with a chosen edge (MCTS.h:470-475)
+    int cur = root, cur_lane = 0, depth = 0;
+    HotRec R = rootrec;
+    const size_t flat = static_cast<size_t>(t) * K + (j < K ? j : 0);
+    int path0 = root, path1 = 0;                      // this lane's path entries: depths sub and sub + 8
+    unsigned n_levels = 0, n_terminal = 0;
+
+    auto is_leaf = [](uint32_t meta) {                // MCTS.h:250-258
+        return !(meta & META_EXPANDED) || (meta & META_TERMINAL) || (meta & META_NEDGE_MASK) == 0;
+    };
+    auto emit = [&]() {                               // MCTS.h:512-544
+        uint32_t lm = R.meta;
+        bool term = (lm & META_TERMINAL) != 0;
+        int code = static_cast<int>((lm & META_RESULT_MASK) >> META_RESULT_SHIFT);
+        if (depth == 0 && !term) {                    // first-time terminal test of a root (MCTS.h:299-319); every descent
+            const int res = G::result(st);            // of the tree finds the same, the first one records it
+            if (res >= 0) {
+                term = true; code = res;
+                lm = (lm & ~META_RESULT_MASK) | META_TERMINAL | (static_cast<uint32_t>(res) << META_RESULT_SHIFT);
+                if (j == 0 && sub == cur_lane) hot[cur].meta = lm;
+            }
+        }
+        if (term) ++n_terminal;
+        uint8_t fl = static_cast<uint8_t>((term ? LEAF_TERMINAL : 0) | (code << LEAF_RESULT_SHIFT));
+        if (depth > 0) fl |= LEAF_VL_APPLIED;
+        if (depth == 0 && !(lm & META_EXPANDED)) fl |= LEAF_ROOT_UNEXPANDED;
+        if (lm & META_EXPANDED) fl |= LEAF_EXPANDED;
+        constexpr uint64_t TOP = 0x0000810204081020ull;               // the top cell of every column
+        const int nv = term ? 0 : 7 - static_cast<int>(__builtin_popcountll((st.bb0 | st.bb1) & TOP));
+        int32_t *path = lf.path + flat * G::MAX_PATH;
+        path[sub] = path0;                                             // entries past depth are ignored downstream
+        path[sub + 8] = path1;
+        if (sub == 0) {
+            lf.slot[flat] = cur; lf.bb0[flat] = st.bb0; lf.bb1[flat] = st.bb1; lf.turn[flat] = st.turn;
+            lf.flags[flat] = fl; lf.path_len[flat] = depth + 1; lf.aux[flat] = st.aux;
+            lf.nvalid[flat] = static_cast<uint8_t>(nv);
+        }
+        done = true;
+    };
+
+    if (!done && is_leaf(R.meta)) emit();             // a root that is a leaf: every descent ends where it starts
+
+    for (int step = 0;; ++step) {
+        // descents of this tree that have left the root already, below this one (their in-flight visits are on it)
+        const unsigned long long pb = __ballot(passed_root);
+        const unsigned tree_groups = static_cast<unsigned>(pb >> (lane & 32)) & 0x01010101u;
+        const bool act = !done && step >= j;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (act) {
+            if (depth == 0)
+                R.n_inflight = rootrec.n_inflight + p.vl_count * static_cast<int>(__builtin_popcount(tree_groups & ((1u << (8 * j)) - 1u)));
+            const uint32_t meta = R.meta;
+            const int E = static_cast<int>((meta & META_NEDGE_MASK) >> META_NEDGE_SHIFT);
+            const bool has = sub < E;
+            const bool is_root = depth == 0;
+            HotRec c = hot[R.child_off + (has ? sub : 0)];
+            float noise = 0.0f;
+            if (is_root && root_mix && has) noise = cold[R.child_off + sub].noise;
+            if (!has) { c.meta = 0u; c.prior = 0.0f; c.child_off = -1; }
+            const bool exists = (c.meta & META_EXISTS) != 0;
+            const bool real = exists && c.n_visits > 0;
+
+            const float pq = mean_q(R.n_visits, R.w_p1, R.w_p2, (meta & META_TURN_P1) != 0);
+            const float seen = group8_ordered_sum7(real ? c.prior : 0.0f);
+            const float scale = (1.0f + pq) / 2.0f;
+            const float eff = p.fpu_reduction * scale;
+            float fpu = fmaf(-eff, sqrtf(seen), pq);
+            fpu = (-1.0f < fpu) ? fpu : -1.0f;
+
+            const int pn_i = R.n_visits + R.n_inflight;
+            const float parent_n = static_cast<float>(pn_i);
+            const float parent_m = mean_m(R.n_visits, R.m_sum);
+            const float c_puct = (pn_i >= 0 && pn_i < p.tab_n)
+                ? p.cpuct_tab[pn_i]
+                : p.c_init + logf((parent_n + p.c_base + 1.0f) / p.c_base);
+            float eff_prior = c.prior;
+            if (is_root && root_mix) eff_prior = fmaf(c.prior, 1.0f - ne, ne * noise);
+
+            float q = fpu, child_q = 0.0f, child_m = 0.0f;
+            int child_total = (exists && c.n_inflight > 0) ? c.n_inflight : 0;
+            if (real) {
+                child_total = c.n_visits + c.n_inflight;
+                child_q = mean_q(c.n_visits, c.w_p1, c.w_p2, (c.meta & META_TURN_P1) != 0);
+                child_m = mean_m(c.n_visits, c.m_sum);
+                q = -child_q;
+            }
+            const float u = c_puct * eff_prior * sqrtf(parent_n) / (1.0f + static_cast<float>(child_total));
+            const float m_util = real ? G::aux_utility(child_m, parent_m, child_q, p) : 0.0f;
+            const float score = q + u + m_util;
+            const int best = group8_argmax(score, has && score == score, lane);
+
+            if (best >= 0) {
+                ++n_levels;
+                if (depth == 0) passed_root = true;                            // MCTS.h:470-475
+                const int src = (lane & 56) + best;
+                const uint32_t bmeta = static_cast<uint32_t>(__shfl(static_cast<int>(c.meta), src));
+                const int b_off = __shfl(c.child_off, src);
+                const int b_n = __shfl(c.n_visits, src);
+                const int b_infl = __shfl(c.n_inflight, src);
+                const float b_w1 = __shfl(c.w_p1, src);
+                const float b_w2 = __shfl(c.w_p2, src);
+                const float b_ms = __shfl(c.m_sum, src);
+                G::step(st, static_cast<int>(bmeta & META_ACTION_MASK));
+                const int res = G::result(st);
+                uint32_t nm = bmeta;
+                if (!(nm & META_EXISTS))                                       // lazy child, MCTS.h:268-275
+                    nm = (nm & ~META_TURN_P1) | META_EXISTS | (st.turn == 1 ? META_TURN_P1 : 0u);
+                if (res >= 0)                                                  // MCTS.h:279-288
+                    nm = (nm & ~META_RESULT_MASK) | META_TERMINAL | (static_cast<uint32_t>(res) << META_RESULT_SHIFT);
+                const int n_infl = b_infl + p.vl_count;                        // MCTS.h:492
+                const int child_slot = R.child_off + best;
+                if (sub == best) {
+                    hot[child_slot].n_inflight = n_infl;
+                    if (nm != bmeta) hot[child_slot].meta = nm;
+                }
+                R.n_visits = b_n; R.n_inflight = n_infl; R.w_p1 = b_w1; R.w_p2 = b_w2; R.m_sum = b_ms;
+                R.child_off = b_off; R.meta = nm;
+                cur = child_slot;
+                cur_lane = best;
+                ++depth;
+                if (depth < 8) { if (sub == depth) path0 = cur; }
+                else if (depth < 16) { if (sub == depth - 8) path1 = cur; }
+                else if (sub == 0) lf.path[flat * G::MAX_PATH + depth] = cur;
+            }
+            if (best < 0 || is_leaf(R.meta)) emit();
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (__all(done)) break;
+    }
+
+    // in-flight visits of the root: one per descent that left it (MCTS.h:470-475)
+    {
+        const unsigned long long pb = __ballot(passed_root);
+        const unsigned tree_groups = static_cast<unsigned>(pb >> (lane & 32)) & 0x01010101u;
+        const int add = p.vl_count * static_cast<int>(__builtin_popcount(tree_groups));
+        if (tree < ar.B && j == 0 && sub == 0 && add != 0) hot[root].n_inflight = rootrec.n_inflight + add;
+    }
+
+    wave_add_counter(counters, CNT_LEVELS, sub == 0 ? n_levels : 0u);
+    wave_add_counter(counters, CNT_TERMINAL, sub == 0 ? n_terminal : 0u);
+    wave_add_counter(counters, CNT_SIMS, (live && sub == 0) ? 1u : 0u);
+}
+
 // ------------------------------------------------------------------ virtual-loss removal
 
 // MCTS.h:561-581: every node of a recorded path (root included) loses vl_count in-flight
@@ -1593,12 +1772,18 @@ void launch_select(int game, TreeArena ar, RootState rs, LeafBuf lf, SearchParam
     static const bool staggered = getenv("AZ_SELECT_STAGGERED") != nullptr && getenv("AZ_SELECT_STAGGERED")[0] == '1';
     // AZ_SELECT_VARIANT: 0 = k_select (the first kernel, every game), 1 = k_select8 (Connect4) without the
     // touches of the grandchildren blocks, 2 (default) = k_select8 with them
-    static const int variant = [] { const char *e = getenv("AZ_SELECT_VARIANT"); return e ? atoi(e) : 2; }();
+    static const int variant = [] { const char *e = getenv("AZ_SELECT_VARIANT"); return e ? atoi(e) : 3; }();
+    // 3 = the K <= 4 virtual-loss descents of a tree side by side (k_select8x4); plain selections use k_select8
+    if (game == Connect4Dev::GAME_ID && variant >= 3 && vl && K >= 2 && K <= 4) {
+        hipLaunchKernelGGL(k_select8x4, dim3(grid_for(ar.B, 2)), dim3(WAVE), 0, s, ar, rs, lf, p, K, counters, bump_call,
+                           reinterpret_cast<long long *>(zero));
+        return;
+    }
     if (game == Connect4Dev::GAME_ID && variant >= 1 && !(vl && staggered)) {
         const int tpw = trees_per_wave(Connect4Dev::LANES);
         const dim3 grid(grid_for(ar.B, tpw)), block(WAVE);
-        if (vl) hipLaunchKernelGGL((k_select8<true>), grid, block, 0, s, ar, rs, lf, p, K, tpw, counters, bump_call, reinterpret_cast<long long *>(zero), variant >= 2 ? 1 : 0);
-        else    hipLaunchKernelGGL((k_select8<false>), grid, block, 0, s, ar, rs, lf, p, K, tpw, counters, bump_call, reinterpret_cast<long long *>(zero), variant >= 2 ? 1 : 0);
+        if (vl) hipLaunchKernelGGL((k_select8<true>), grid, block, 0, s, ar, rs, lf, p, K, tpw, counters, bump_call, reinterpret_cast<long long *>(zero), variant == 2 ? 1 : 0);
+        else    hipLaunchKernelGGL((k_select8<false>), grid, block, 0, s, ar, rs, lf, p, K, tpw, counters, bump_call, reinterpret_cast<long long *>(zero), variant == 2 ? 1 : 0);
         return;
     }
     if (vl && staggered && K >= 2 && K <= 4 && game == Connect4Dev::GAME_ID) {
