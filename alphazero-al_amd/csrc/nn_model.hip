@@ -22,15 +22,17 @@ struct az_nn_model {
 namespace {
 constexpr int64_t kTokenBytes = 42 * 64 * 2;     // one sample's (42, 64) bf16 activations
 
-// az_nn_model_profile: event pairs around the FIRST residual block of every stride-th forward call
-// (process-wide; the mutex only matters when several streams share the model)
+// az_nn_model_profile: event pairs around the launches of every stride-th forward call - the stem, the
+// FIRST residual block, the attention block and the heads, one ring per kind (process-wide; the
+// mutex only matters when several streams share the model)
+constexpr int kKinds = 4;                         // AZ_NN_PROFILE_*
 struct Profile {
     std::mutex mu;
     bool on = false;
     int stride = 1;
     int64_t seen = 0;
-    std::vector<hipEvent_t> start, stop;
-    size_t used = 0;
+    std::vector<hipEvent_t> start[kKinds], stop[kKinds];
+    size_t used[kKinds] = {0, 0, 0, 0};
 } g_prof;
 constexpr size_t kProfileMax = 4096;
 
@@ -173,29 +175,43 @@ int az_nn_model_forward(const az_nn_model *m, const float *features, const uint8
     const az_nn_model_weights &w = m->w;
     char *a = static_cast<char *>(scratch);
     char *b = a + batch * kTokenBytes;
-    int rc = az_nn_stem_embed(features, w.emb_own, w.emb_opp, w.pos, w.stem_w, w.stem_b, a, batch, rows, n_rows, stream);
-    for (int i = 0; rc == 0 && i < w.n_blocks; ++i) {
-        int slot = -1;
-        if (i == 0 && g_prof.on) {
-            std::lock_guard<std::mutex> lk(g_prof.mu);
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            const bool capturing = hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
-            if (g_prof.on && !capturing && (g_prof.seen++ % g_prof.stride) == 0 && g_prof.used < g_prof.start.size()) {
-                slot = static_cast<int>(g_prof.used++);
-                (void)hipEventRecord(g_prof.start[slot], static_cast<hipStream_t>(stream));
-            }
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    // this call carries event pairs?  (never while the stream is capturing: no timestamps there)
+    bool timed = false;
+    int slot[kKinds] = {-1, -1, -1, -1};
+    if (g_prof.on) {
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        const bool capturing = hipStreamIsCapturing(hs, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+        if (g_prof.on && !capturing && (g_prof.seen++ % g_prof.stride) == 0) {
+            timed = true;
+            for (int kd = 0; kd < kKinds; ++kd)
+                if (g_prof.used[kd] < g_prof.start[kd].size()) slot[kd] = static_cast<int>(g_prof.used[kd]++);
         }
+    }
+    auto begin = [&](int kd) { if (timed && slot[kd] >= 0) (void)hipEventRecord(g_prof.start[kd][slot[kd]], hs); };
+    auto end = [&](int kd) { if (timed && slot[kd] >= 0) (void)hipEventRecord(g_prof.stop[kd][slot[kd]], hs); };
+    begin(AZ_NN_PROFILE_STEM);
+    int rc = az_nn_stem_embed(features, w.emb_own, w.emb_opp, w.pos, w.stem_w, w.stem_b, a, batch, rows, n_rows, stream);
+    end(AZ_NN_PROFILE_STEM);
+    for (int i = 0; rc == 0 && i < w.n_blocks; ++i) {
+        if (i == 0) begin(AZ_NN_PROFILE_CONV);
         rc = az_nn_conv_block(a, 64, w.block_w[i], w.block_b[i], w.block_gamma[i], w.block_beta[i], 1, b, batch,
                               w.eps, n_rows, stream);
-        if (slot >= 0) (void)hipEventRecord(g_prof.stop[slot], static_cast<hipStream_t>(stream));
+        if (i == 0) end(AZ_NN_PROFILE_CONV);
         char *t = a; a = b; b = t;
     }
     if (rc == 0) {
+        begin(AZ_NN_PROFILE_ATTN);
         rc = az_nn_attn_block(a, w.pre_w, w.qkvg_w, w.qn_w, w.kn_w, w.o_w, b, batch, w.eps, n_rows, stream);
+        end(AZ_NN_PROFILE_ATTN);
         char *t = a; a = b; b = t;
     }
-    if (rc == 0)
+    if (rc == 0) {
+        begin(AZ_NN_PROFILE_HEADS);
         rc = az_nn_heads(a, &w.heads, mask, probs, wdl, moves_left, batch, w.eps, rows, n_rows, stream);
+        end(AZ_NN_PROFILE_HEADS);
+    }
     return rc;
 }
 
@@ -203,11 +219,12 @@ int az_nn_model_profile(int enable)
 {
     std::lock_guard<std::mutex> lk(g_prof.mu);
     if (enable) {
-        while (g_prof.start.size() < kProfileMax) {
-            hipEvent_t a, b;
-            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return 2;
-            g_prof.start.push_back(a); g_prof.stop.push_back(b);
-        }
+        for (int kd = 0; kd < kKinds; ++kd)
+            while (g_prof.start[kd].size() < kProfileMax) {
+                hipEvent_t a, b;
+                if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return 2;
+                g_prof.start[kd].push_back(a); g_prof.stop[kd].push_back(b);
+            }
     }
     g_prof.on = enable != 0;
     g_prof.stride = enable > 1 ? enable : 1;
@@ -215,20 +232,33 @@ int az_nn_model_profile(int enable)
     return 0;
 }
 
-int az_nn_model_profile_read(double *out_ms, int64_t *out_launches)
+int az_nn_model_profile_read_kernels(double out_ms[4], int64_t out_launches[4])
 {
     if (out_ms == nullptr || out_launches == nullptr) return 1;
     if (hipDeviceSynchronize() != hipSuccess) return 2;
     std::lock_guard<std::mutex> lk(g_prof.mu);
-    double ms = 0.0;
-    for (size_t i = 0; i < g_prof.used; ++i) {
-        float t = 0.f;
-        if (hipEventElapsedTime(&t, g_prof.start[i], g_prof.stop[i]) != hipSuccess) return 2;
-        ms += t;
+    for (int kd = 0; kd < kKinds; ++kd) {
+        double ms = 0.0;
+        for (size_t i = 0; i < g_prof.used[kd]; ++i) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, g_prof.start[kd][i], g_prof.stop[kd][i]) != hipSuccess) return 2;
+            ms += t;
+        }
+        out_ms[kd] = ms;
+        out_launches[kd] = static_cast<int64_t>(g_prof.used[kd]);
+        g_prof.used[kd] = 0;
     }
-    *out_ms = ms;
-    *out_launches = static_cast<int64_t>(g_prof.used);
-    g_prof.used = 0;
+    return 0;
+}
+
+int az_nn_model_profile_read(double *out_ms, int64_t *out_launches)
+{
+    if (out_ms == nullptr || out_launches == nullptr) return 1;
+    double ms[4]; int64_t n[4];
+    const int rc = az_nn_model_profile_read_kernels(ms, n);
+    if (rc != 0) return rc;
+    *out_ms = ms[AZ_NN_PROFILE_CONV];
+    *out_launches = n[AZ_NN_PROFILE_CONV];
     return 0;
 }
 

@@ -6,7 +6,38 @@ the device and a HIP kernel all produce bit-identical policy / WDL / moves-left 
 (tests/scenarios.py holds the numpy twin).  Used to check the fused search path bit-for-bit
 against the CPU oracle and to benchmark the tree kernels without a network.
 """
+import numpy as np
 import torch
+
+
+class NumpyHashEvaluator:
+    """The same function on the host in numpy, behind the reference's `predict(state, action_mask)`
+    contract (Connect4/Network.py:267-288): the evaluator of bench.py's tree-only CPU baseline."""
+    n_actions = 7
+
+    def predict(self, state, action_mask=None):
+        state = np.asarray(state)
+        turns = state[:, 2, 0, 0].astype(np.int64)
+        grid = ((state[:, 0] - state[:, 1]) * turns[:, None, None]).astype(np.int8)
+        rows, cols = np.arange(6).reshape(1, 6, 1), np.arange(7).reshape(1, 1, 7)
+        bit = (np.uint64(1) << (cols * 7 + (5 - rows)).astype(np.uint64))
+        bb0 = (bit * (grid == 1)).sum((1, 2), dtype=np.uint64)
+        bb1 = (bit * (grid == -1)).sum((1, 2), dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            x = bb0 * np.uint64(0x9E3779B97F4A7C15)
+            x ^= (bb1 + np.uint64(0x7F4A7C159E3779B9)) * np.uint64(0xBF58476D1CE4E5B9)
+            x += np.where(turns == 1, np.uint64(0x94D049BB133111EB), np.uint64(0x2545F4914F6CDD1D))
+            x ^= x >> np.uint64(30); x *= np.uint64(0xBF58476D1CE4E5B9)
+            x ^= x >> np.uint64(27); x *= np.uint64(0x94D049BB133111EB)
+            x ^= x >> np.uint64(31)
+        sh = (np.arange(7) * 4).astype(np.uint64)
+        probs = (1 + ((x[:, None] >> sh) & np.uint64(15))).astype(np.float32) / np.float32(16)
+        if action_mask is not None:
+            probs = probs * np.asarray(action_mask, dtype=np.float32)
+        w = np.stack([1 + ((x >> np.uint64(s)) & np.uint64(31)) for s in (28, 33, 38)], 1)
+        wdl = w.astype(np.float32) / w.sum(1, keepdims=True).astype(np.float32)
+        ml = ((x >> np.uint64(43)) & np.uint64(63)).astype(np.float32) / np.float32(2)
+        return probs, wdl.astype(np.float32), ml.reshape(-1, 1)
 
 
 def _c(v):

@@ -61,6 +61,12 @@ def host_cores():
 PROFILE_EVERY = 4
 
 
+def select_kernel_name():
+    """The selection kernel a virtual-loss launch runs (kernels.hip launch_select, AZ_SELECT_VARIANT)."""
+    v = int(os.environ.get("AZ_SELECT_VARIANT", "3"))
+    return {0: "k_select<Connect4Dev,true>", 1: "k_select8<true>", 2: "k_select8<true>+touch"}.get(v, "k_select8x4")
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,7 +133,12 @@ import importlib.util
 spec = importlib.util.spec_from_file_location('az_net', os.path.join({PKG!r}, 'src', 'az_net.py'))
 N = importlib.util.module_from_spec(spec); spec.loader.exec_module(N)
 torch.manual_seed(0); torch.set_num_threads({cores})
-net = N.Connect4Net(device='cpu').eval()
+if {args.evaluator!r} == 'hash':
+    spec = importlib.util.spec_from_file_location('az_hash', os.path.join({PKG!r}, 'src', 'hash_eval.py'))
+    H = importlib.util.module_from_spec(spec); spec.loader.exec_module(H)
+    net = H.NumpyHashEvaluator()                # tree-only leg: the integer-hash evaluator in numpy
+else:
+    net = N.Connect4Net(device='cpu').eval()
 B, n, K, plies = {games}, {args.n_playout}, {args.vl_batch}, {args.cpu_plies}
 w = W.BatchedMCTS(B, c_init=1.4, c_base=5*n, alpha=0.3, n_playout=n, noise_epsilon=0.25,
                   fpu_reduction=0.2, use_symmetry=True, mlh_slope=0.1, mlh_cap=0.2)
@@ -155,9 +166,12 @@ print(json.dumps(dict(value=B*plies/dt, seconds=dt, positions=B*plies)))
         return None
     what = (f"reference C++/OpenMP search (oracle/_ref/{os.path.basename(ref_dir)})" if kind == "reference"
             else "oracle/ C restatement of the reference search, one thread")
+    ev = (f"same CNN fp32 on CPU ({cores} torch threads)" if args.evaluator == "cnn"
+          else "integer-hash evaluator in numpy (tree-only leg)")
     return {"value": round(r["value"], 2), "unit": "positions/s", "cores": cores, "kind": kind,
-            "sample": f"{games} games x {args.cpu_plies} plies, n_playout={args.n_playout}, "
-                      f"vl_batch={args.vl_batch}, {what} + same CNN fp32 on CPU ({cores} torch threads), {r['seconds']:.1f} s"}
+            "sample": f"{games} games x {args.cpu_plies} plies from EMPTY boards (openings only: shallower trees and no "
+                      f"terminal leaves, a lighter mix than the GPU leg's games of all ages), n_playout={args.n_playout}, "
+                      f"vl_batch={args.vl_batch}, {what} + {ev}, {r['seconds']:.1f} s"}
 
 
 def conv_roofline(torch, fast, leaves, launches=20):
@@ -272,9 +286,11 @@ def main():
     elapsed = time.perf_counter() - t0
     log(f"timed region: {args.steps} steps in {elapsed:.2f} s")
 
-    conv_ms, conv_n = C.c_double(), C.c_int64()
-    G.az_nn_model_profile_read(C.byref(conv_ms), C.byref(conv_n))
+    G.az_nn_model_profile_read_kernels.argtypes = [C.POINTER(C.c_double * 4), C.POINTER(C.c_int64 * 4)]
+    ev_ms, ev_n = (C.c_double * 4)(), (C.c_int64 * 4)()
+    G.az_nn_model_profile_read_kernels(C.byref(ev_ms), C.byref(ev_n))
     G.az_nn_model_profile(0)
+    conv_ms, conv_n = C.c_double(ev_ms[1]), C.c_int64(ev_n[1])
     ms = [0.0, 0.0]; nl = [0, 0]
     for h in handles:
         ms_h = (C.c_double * 2)(); nl_h = (C.c_int64 * 2)()
@@ -317,11 +333,16 @@ def main():
             raw_ms = sel_ms / sel_n
             avg_ms = max(raw_ms - pair_ms, raw_ms * 0.25)
             achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
+            # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes,
+            # tools/collect_traffic.py): a stored measurement is only quoted for the configuration it was
+            # taken on - kernel, trees per launch, n_playout, K, streams, evaluator - otherwise null
             traffic = None
+            traffic_key = "%s|games=%d|n_playout=%d|K=%d|streams=%d|evaluator=%s|lead_in=%d" % (
+                select_kernel_name(), args.games, args.n_playout, args.vl_batch, args.streams, args.evaluator, args.lead_in)
             tf = os.path.join(ROOT, "profiles", "traffic_select.json")
             if os.path.exists(tf):
                 try:
-                    traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+                    traffic = json.load(open(tf)).get("by_config", {}).get(traffic_key, {}).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
             # achievable copy bandwidth on this box (SURVEY 8d asks for it beside the datasheet peak)
@@ -337,8 +358,8 @@ def main():
             copy_gbs = 5 * 2 * (1 << 30) / (c0.elapsed_time(c1) * 1e-3) / 1e9
             del src, dst
             roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                        "kernel": "k_select<VL>", "avg_launch_us": round(avg_ms * 1e3, 2),
+                        "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_key": traffic_key,
+                        "kernel": select_kernel_name(), "avg_launch_us": round(avg_ms * 1e3, 2),
                         "avg_event_pair_us": round(raw_ms * 1e3, 2), "empty_event_pair_us": round(pair_ms * 1e3, 2),
                         "launches_timed": sel_n, "algorithmic_bytes_per_launch": int(per_launch_bytes),
                         "measured_copy_GBs": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 6),
@@ -349,7 +370,8 @@ def main():
                                     "isolated time (--streams 1: one launch over all trees, profiles/README.md)"
                                     % (args.streams, args.games // args.streams))
         out = {
-            "metric": "self-play positions/sec (Connect4 n_playout=200, batch=8192 games/GPU, vl_batch=4)",
+            "metric": "self-play positions/sec (Connect4 n_playout=%d, batch=%d games/GPU, vl_batch=%d%s)"
+                      % (args.n_playout, args.games, args.vl_batch, "" if args.evaluator == "cnn" else ", tree kernels only: integer-hash evaluator"),
             "value": round(g_pos / t, 2), "unit": "positions/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(t / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
@@ -393,6 +415,34 @@ def main():
                     "synthetic_launch": {"achieved": synth["achieved"], "avg_launch_us": synth["avg_launch_us"],
                                          "leaves": args.games * args.vl_batch // max(args.streams, 1),
                                          "note": "same kernel on random activations after the run: slower, the clock follows the data"}}
+                # every kernel of the evaluator, same event pairs, same timed region.  FLOPs per leaf from the layer
+                # shapes (Network.py:27-93,96-141): stem 42 x 64 x 288 MACs, residual block 42 x 64 x 576, attention
+                # 42 x 196 x 64 (QKVG) + 2 x 4 x 42 x 42 x 16 (scores, PV) + 42 x 64 x 64 (out); the heads are
+                # pooling + 64-wide linears on a few vectors: memory traffic, not matrix work, bounds them.
+                act = 42 * 64 * 2                                  # one sample's bf16 activations
+                pair = roofline["empty_event_pair_us"] if roofline else 0.0
+                table = []
+                for idx, name, flops_leaf, bytes_leaf in (
+                        (0, "k_conv_block<32,..,EMBED> (stem + embedding)", 2.0 * 42 * 64 * 288, 504 + act),
+                        (1, "k_conv_block<64,norm,residual> (x3 per forward)", 2.0 * 42 * 64 * 576, 2 * act),
+                        (2, "k_attn_block", 2.0 * (42 * 196 * 64 + 2 * 4 * 42 * 42 * 16 + 42 * 64 * 64), 2 * act),
+                        (3, "k_heads", 2.0 * (42 * 64 + 9 * 64 * 64 + 4 * 64 * 64 + 64 * 46), act + 7 + 44)):
+                    if ev_n[idx] <= 0:
+                        continue
+                    raw = ev_ms[idx] / ev_n[idx] * 1e3
+                    us_k = max(raw - pair, raw * 0.25)
+                    tf_s = flops_leaf * live / (us_k * 1e-6) / 1e12
+                    gb_s = bytes_leaf * live / (us_k * 1e-6) / 1e9
+                    bound = "mfma" if tf_s / 2500.0 >= gb_s / HBM_PEAK_GBS else "hbm"
+                    table.append({"kernel": name, "avg_launch_us": round(us_k, 1), "launches_timed": int(ev_n[idx]),
+                                  "bound": bound,
+                                  "achieved": round(tf_s if bound == "mfma" else gb_s, 1),
+                                  "peak": 2500.0 if bound == "mfma" else HBM_PEAK_GBS,
+                                  "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+                                  "frac": round(max(tf_s / 2500.0, gb_s / HBM_PEAK_GBS), 4),
+                                  "frac_mfma": round(tf_s / 2500.0, 4), "frac_hbm": round(gb_s / HBM_PEAK_GBS, 4),
+                                  "flops_per_launch": int(flops_leaf * live), "algorithmic_bytes_per_launch": int(bytes_leaf * live)})
+                out["roofline_evaluator_kernels"] = table
             else:
                 out["roofline_evaluator"] = synth
         if args.table:

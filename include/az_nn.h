@@ -140,6 +140,14 @@ int az_nn_model_forward(const az_nn_model *m, const float *features, const uint8
  * synchronises the device and returns the summed milliseconds and the number of launches summed. */
 int az_nn_model_profile(int enable);
 int az_nn_model_profile_read(double *out_ms, int64_t *out_launches);
+/* The same for every kernel kind of the forward pass: the stem, the first residual block, the attention
+ * block, the heads (an event pair around each on every n-th call): summed milliseconds and launches
+ * per kind, in the order of AZ_NN_PROFILE_*.  Reading empties the rings (either reader). */
+#define AZ_NN_PROFILE_STEM  0
+#define AZ_NN_PROFILE_CONV  1
+#define AZ_NN_PROFILE_ATTN  2
+#define AZ_NN_PROFILE_HEADS 3
+int az_nn_model_profile_read_kernels(double out_ms[4], int64_t out_launches[4]);
 
 /* One 3x3 convolution layer of the reference's Othello network (Othello/Network.py:22-66,129-139:
  * 256 output channels on 10x10 / 8x8 maps) as an implicit-GEMM MFMA kernel (nn_othello.hip):
