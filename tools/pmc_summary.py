@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    name = name.replace("az::(anonymous namespace)::", "").replace("void ", "")
+    name = name.replace("az::(anonymous namespace)::", "").replace("(anonymous namespace)::", "").replace("void ", "")
     cut = name.find("(")
     return name[:cut] if cut > 0 else name
 
