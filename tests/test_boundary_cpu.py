@@ -307,6 +307,23 @@ def test_reference_selfplay_harness_g8(built, monkeypatch):
                 assert np.array_equal(got, ref), (i, nm)
 
 
+def test_restated_selfplay_harness_g8(built, monkeypatch):
+    """tests/harness.py - the restatement of Game.batch_self_play + get_batch_action that the GPU suite
+    runs on the HIP engine (the reference's files do not exist on the GPU box) - reproduces fixture G8
+    on our wrapper and Env objects, the oracle standing in for the native backend."""
+    import harness
+    from src import MCTS_cpp
+    monkeypatch.setitem(MCTS_cpp._BACKENDS, "Connect4", _OracleBackend)
+    from src.env_cpp.connect4 import Env
+    np.random.seed(11)
+    w = MCTS_cpp.BatchedMCTS(8, c_init=1.4, c_base=160, alpha=0.3, n_playout=32, noise_epsilon=0.25, fpu_reduction=0.2,
+                             use_symmetry=True, mlh_slope=0.1, mlh_cap=0.2)
+    w.seed(21)
+    data = harness.batch_self_play(w, S.HashPV(), Env, 8, temperature=1.0, temp_decay_moves=6, temp_endgame=0, td_steps=2,
+                                   vl_batch=4)
+    harness.check_against_g8(data, load("g8_selfplay"), bits)
+
+
 def test_othello_env_against_reference_fixture(built):
     from src.env_cpp.othello import Env
     from test_oracle_golden import replay_othello_env

@@ -115,6 +115,23 @@ def test_wrapper_g6_on_engine(mcts_cpp):
         _replay_g6(MCTS_cpp.BatchedMCTS, tag, cache, K, seed)
 
 
+def test_selfplay_harness_g8_on_the_hip_engine(mcts_cpp):
+    """Fixture G8 - what the reference's `Game.batch_self_play` + `AlphaZeroPlayer` returned on the
+    compiled reference (8 games, actor configuration: noise, symmetry, virtual loss, temperature
+    schedule, td_steps 2) - reproduced by the same harness (tests/harness.py, checked against the
+    reference's own files in the CPU suite) on OUR wrapper, OUR Env objects and the HIP engine."""
+    import harness
+    from src import MCTS_cpp
+    from src.env_cpp.connect4 import Env
+    np.random.seed(11)
+    w = MCTS_cpp.BatchedMCTS(8, c_init=1.4, c_base=160, alpha=0.3, n_playout=32, noise_epsilon=0.25, fpu_reduction=0.2,
+                             use_symmetry=True, mlh_slope=0.1, mlh_cap=0.2)
+    w.seed(21)
+    data = harness.batch_self_play(w, S.HashPV(), Env, 8, temperature=1.0, temp_decay_moves=6, temp_endgame=0, td_steps=2,
+                                   vl_batch=4)
+    harness.check_against_g8(data, load("g8_selfplay"), bits)
+
+
 def test_error_behaviour(mcts_cpp):
     m = mcts_cpp.BatchedMCTS_Connect4(8)
     b = np.zeros((8, 6, 7), np.int8); t = np.ones(8, np.int32)
