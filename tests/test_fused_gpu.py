@@ -141,9 +141,22 @@ def test_fast_inference_twin_g7(env):
     p, w, ml = FastConnect4Net.from_module(net, dtype=torch.float32).predict(planes, masks)
     assert np.abs(p - g["ckpt_probs"]).max() < 1e-4 and np.abs(w - g["ckpt_wdl"]).max() < 1e-4
     assert np.abs(ml - g["ckpt_ml"]).max() < 1e-2
+    # bf16: the yardstick is the reference's OWN bf16 path on the same inputs (the module under autocast,
+    # Network.py:275): measured on MI355X it is 1.6e-2 max / 8.9e-4 mean off its fp32 outputs on the policy
+    # and 3.4e-2 / 1.4e-3 on WDL; the HIP twin 2.3e-2 / 7.7e-4 and 4.5e-2 / 1.3e-3, arg-max move identical
+    # to fp32 on all 256 positions.  Bounds: means no worse than 1.25x the module's, maxima within 1.5x of
+    # its worst (3.4e-2), i.e. 5e-2 - not the 8e-2 of round 1.
+    pm, wm, _ = net.predict(planes, masks)
     p, w, ml = FastConnect4Net.from_module(net).predict(planes, masks)
-    assert np.abs(p - g["ckpt_probs"]).max() < 8e-2 and np.abs(p - g["ckpt_probs"]).mean() < 5e-3
-    assert np.abs(w - g["ckpt_wdl"]).max() < 8e-2 and np.abs(w - g["ckpt_wdl"]).mean() < 5e-3
+    e = dict(p_max=np.abs(p - g["ckpt_probs"]).max(), p_mean=np.abs(p - g["ckpt_probs"]).mean(),
+             w_max=np.abs(w - g["ckpt_wdl"]).max(), w_mean=np.abs(w - g["ckpt_wdl"]).mean(),
+             ref_p_mean=np.abs(pm - g["ckpt_probs"]).mean(), ref_w_mean=np.abs(wm - g["ckpt_wdl"]).mean(),
+             ref_p_max=np.abs(pm - g["ckpt_probs"]).max(), ref_w_max=np.abs(wm - g["ckpt_wdl"]).max(),
+             argmax=(p.argmax(1) == g["ckpt_probs"].argmax(1)).mean())
+    print("twin vs G7:", {k: round(float(v), 5) for k, v in e.items()})
+    assert e["p_max"] < 3e-2 and e["w_max"] < 5e-2, e
+    assert e["p_mean"] < 1.25 * e["ref_p_mean"] + 1e-4 and e["w_mean"] < 1.25 * e["ref_w_mean"] + 1e-4, e
+    assert e["argmax"] >= 0.99, e
     # weight updates on the source module are picked up by the fused path
     w_ = env["W"].BatchedMCTS(8, 1.4, 100, 0.0, 9, noise_epsilon=0.0, use_symmetry=False)
     b, t = S.random_openings(np.random.default_rng(1), 8, 4)
@@ -384,9 +397,9 @@ def test_fast_net_hip_path_equals_torch_path(env):
     p1, w1, m1 = fast.predict(planes, masks)
     fast.hip = False
     p2, w2, m2 = fast.predict(planes, masks)
-    assert np.abs(p1 - p2).max() < 5e-2 and np.abs(w1 - w2).max() < 5e-2 and np.abs(m1 - m2).max() < 2.0
-    assert np.abs(p1 - g["ckpt_probs"]).max() < 8e-2 and np.abs(p1 - g["ckpt_probs"]).mean() < 5e-3
-    assert np.abs(w1 - g["ckpt_wdl"]).max() < 8e-2 and np.abs(w1 - g["ckpt_wdl"]).mean() < 5e-3
+    assert np.abs(p1 - p2).max() < 4e-2 and np.abs(w1 - w2).max() < 5e-2 and np.abs(m1 - m2).max() < 2.0
+    assert np.abs(p1 - g["ckpt_probs"]).max() < 3e-2 and np.abs(p1 - g["ckpt_probs"]).mean() < 1.5e-3
+    assert np.abs(w1 - g["ckpt_wdl"]).max() < 5e-2 and np.abs(w1 - g["ckpt_wdl"]).mean() < 2.5e-3
 
 
 def test_fused_with_network_statistical_agreement(env):
@@ -407,8 +420,11 @@ def test_fused_with_network_statistical_agreement(env):
     (c1, s1), (c2, s2) = res
     assert (s1[:, 0] == 200).all() and (s2[:, 0] == 200).all()
     assert (c1.sum(1) == 199).all() and (c2.sum(1) == 199).all()
-    assert np.abs(s1[:, 1] - s2[:, 1]).mean() < 0.05          # root Q
-    assert (np.argmax(c1, 1) == np.argmax(c2, 1)).mean() > 0.8
+    q_gap = float(np.abs(s1[:, 1] - s2[:, 1]).mean())
+    agree = float((np.argmax(c1, 1) == np.argmax(c2, 1)).mean())
+    dist = float(np.abs(c1 / 199.0 - c2 / 199.0).sum(1).mean()) / 2          # total-variation distance of the visit distributions
+    print("fused vs host with the network: root-Q gap %.4f, arg-max agreement %.3f, TV distance %.4f" % (q_gap, agree, dist))
+    assert q_gap < 0.02 and agree > 0.95 and dist < 0.03       # measured on MI355X: 0.0076, 1.000, 0.0070
 
 
 def test_device_transposition_table_leaves_the_search_unchanged(env):
