@@ -149,8 +149,18 @@ struct az_mcts {
     DevBuf<az::HotRec> hot;
     DevBuf<az::ColdRec> cold;
     DevBuf<int32_t> root, used;
-    int64_t S = 0;
+    DevBuf<uint8_t> half;     // which of its two arena halves a tree lives in (tree_layout.h)
+    int64_t S = 0;            // records per half
     int64_t used_bound = 1;   // host-side upper bound of max(used[])
+    // What the trees occupy after a re-rooting, reported by the prune kernel without stalling the host:
+    // prune number q leaves its maximum in live_ring[q % 8] (pinned host memory) through an async copy;
+    // growth_after[q % 8] sums the room handed out by ensure_room since that prune was issued, so that
+    // `arrived value + growth since` is an upper bound of max(used[]) again.
+    DevBuf<int> max_live;
+    volatile int *live_ring = nullptr;
+    int64_t prune_seq = 0;
+    int64_t ring_seq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t growth_after[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t epoch = 0;        // bumped whenever a buffer the dev_* kernels address moves
 
     // roots of the current call
@@ -215,7 +225,7 @@ struct az_mcts {
     az::TreeArena arena()
     {
         az::TreeArena a;
-        a.hot = hot.p; a.cold = cold.p; a.root = root.p; a.used = used.p; a.S = S; a.B = B;
+        a.hot = hot.p; a.cold = cold.p; a.half = half.p; a.root = root.p; a.used = used.p; a.S = S; a.B = B;
         return a;
     }
     az::RootState roots()
@@ -292,26 +302,46 @@ struct az_mcts {
         const int64_t keep = std::min<int64_t>(S, true_max_used());
         DevBuf<az::HotRec> nh;
         DevBuf<az::ColdRec> nc;
-        nh.ensure(static_cast<size_t>(B) * new_S);
-        nc.ensure(static_cast<size_t>(B) * new_S);
+        nh.ensure(static_cast<size_t>(B) * 2 * new_S);
+        nc.ensure(static_cast<size_t>(B) * 2 * new_S);
+        // one row per half (slots are relative to a half: nothing to renumber)
         HIP_OK(hipMemcpy2D(nh.p, new_S * sizeof(az::HotRec), hot.p, S * sizeof(az::HotRec),
-                           keep * sizeof(az::HotRec), B, hipMemcpyDeviceToDevice));
+                           keep * sizeof(az::HotRec), static_cast<size_t>(B) * 2, hipMemcpyDeviceToDevice));
         HIP_OK(hipMemcpy2D(nc.p, new_S * sizeof(az::ColdRec), cold.p, S * sizeof(az::ColdRec),
-                           keep * sizeof(az::ColdRec), B, hipMemcpyDeviceToDevice));
+                           keep * sizeof(az::ColdRec), static_cast<size_t>(B) * 2, hipMemcpyDeviceToDevice));
         std::swap(hot.p, nh.p); std::swap(hot.n, nh.n);
         std::swap(cold.p, nc.p); std::swap(cold.n, nc.n);
         S = new_S;
         ++epoch;
     }
 
+    // the newest re-rooting whose occupancy figure has arrived tightens the host-side bound
+    void tighten_bound()
+    {
+        for (int64_t q = prune_seq; q > 0 && q > prune_seq - 8; --q) {
+            const int v = live_ring[q % 8];
+            if (ring_seq[q % 8] == q && v >= 0) {
+                used_bound = std::min<int64_t>(used_bound, static_cast<int64_t>(v) + growth_after[q % 8]);
+                return;
+            }
+        }
+    }
+    bool room_needs_device(int64_t extra)
+    {
+        if (used_bound + extra > S) tighten_bound();
+        return used_bound + extra > S;
+    }
+
     // room for `extra` more records in every tree (an expansion appends at most A records)
     void ensure_room(int64_t extra)
     {
+        if (used_bound + extra > S) tighten_bound();
         if (used_bound + extra > S) {
             used_bound = true_max_used();
             if (used_bound + extra > S) grow(std::max<int64_t>(2 * S, used_bound + extra));
         }
         used_bound += extra;
+        for (auto &g : growth_after) g += extra;
     }
 
     void check_device_error()
@@ -332,7 +362,25 @@ struct az_mcts {
         if (msg.empty()) msg = "device error word " + std::to_string(e);
         return msg;
     }
-    ~az_mcts() { if (err_host) (void)hipHostFree(err_host); }
+    // re-rooting on `s` (k_prune: the kept subtrees move to the other arena halves); its occupancy figure
+    // travels to live_ring behind it
+    void prune_on(const int32_t *actions_dev, int32_t *noise_req, bool dev_noise, const float *noise_replay, hipStream_t s)
+    {
+        const int64_t q = ++prune_seq;
+        // the slot's previous figure (prune q - 8) must have landed before the slot is handed out again
+        if (ring_seq[q % 8] != 0 && live_ring[q % 8] < 0) HIP_OK(hipStreamSynchronize(s));
+        live_ring[q % 8] = -1;
+        ring_seq[q % 8] = q;
+        growth_after[q % 8] = 0;
+        HIP_OK(hipMemsetAsync(max_live.p, 0, sizeof(int), s));
+        az::launch_prune(game, arena(), params(), actions_dev, noise_req, dev_noise, s, noise_replay, max_live.p, err.p);
+        HIP_OK(hipMemcpyAsync(const_cast<int *>(&live_ring[q % 8]), max_live.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    }
+    ~az_mcts()
+    {
+        if (err_host) (void)hipHostFree(err_host);
+        if (live_ring) (void)hipHostFree(const_cast<int *>(live_ring));
+    }
 };
 
 namespace {
@@ -359,9 +407,16 @@ az_mcts *create_engine(int game, int n_envs, int device)
         m->cfg.mlh_cap = 0.2f; m->cfg.score_utility_factor = 0.0f; m->cfg.score_scale = 8.0f;
         m->cfg.value_decay = 1.0f; m->cfg.use_symmetry = 1; m->cfg.vl_count = 1;
         m->S = kInitialSlots;
-        m->hot.ensure(static_cast<size_t>(n_envs) * m->S);
-        m->cold.ensure(static_cast<size_t>(n_envs) * m->S);
-        m->root.ensure(n_envs); m->used.ensure(n_envs);
+        m->hot.ensure(static_cast<size_t>(n_envs) * 2 * m->S);
+        m->cold.ensure(static_cast<size_t>(n_envs) * 2 * m->S);
+        m->root.ensure(n_envs); m->used.ensure(n_envs); m->half.ensure(n_envs, true);
+        m->max_live.ensure(1, true);
+        {
+            int *ring = nullptr;
+            HIP_OK(hipHostMalloc(reinterpret_cast<void **>(&ring), 8 * sizeof(int), hipHostMallocDefault));
+            for (int i = 0; i < 8; ++i) ring[i] = -1;
+            m->live_ring = ring;
+        }
         m->r_bb0.ensure(n_envs, true); m->r_bb1.ensure(n_envs, true);
         m->r_turn.ensure(n_envs, true); m->r_last.ensure(n_envs, true);
         m->counters.ensure(az::CNT_N * az::CNT_STRIPES, true);
@@ -597,8 +652,7 @@ int az_mcts_prune_roots(az_mcts *m, const int32_t *actions, int64_t n)
         const int A = m->geo.actions;
         m->io_actions.ensure(B); m->io_noise_req.ensure(B, true);
         HIP_OK(hipMemcpy(m->io_actions.p, actions, sizeof(int32_t) * B, hipMemcpyHostToDevice));
-        const az::SearchParams p = m->params();
-        az::launch_prune(m->game, m->arena(), p, m->io_actions.p, m->io_noise_req.p, false, s);
+        m->prune_on(m->io_actions.p, m->io_noise_req.p, false, nullptr, s);
         if (m->cfg.dirichlet_alpha > 0.0f) {  // apply_root_noise, env order (MCTS.h:113-132)
             std::vector<int32_t> req(B);
             HIP_OK(hipMemcpy(req.data(), m->io_noise_req.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
@@ -856,7 +910,7 @@ void dev_prepare(az_mcts *m, int K, int64_t sims_per_tree, hipStream_t s, bool w
     // runs ahead of the real fill by at most one call's worth).
     const bool touches = m->any_pending_reset || total > m->vl_leaf.slot.n || static_cast<size_t>(m->B) > m->plain_leaf.slot.n ||
                          !m->tab.p || !m->term_tab.p || m->cfg.c_init != m->tab_c_init || m->cfg.c_base != m->tab_c_base ||
-                         m->cfg.score_scale != m->term_tab_scale || m->used_bound + extra > m->S;
+                         m->cfg.score_scale != m->term_tab_scale || m->room_needs_device(extra);
     if (touches) {
         if (whole_device) HIP_OK(hipDeviceSynchronize());
         else HIP_OK(hipStreamSynchronize(s));
@@ -1009,7 +1063,7 @@ int az_mcts_dev_search(az_mcts *m, const az_nn_model *model, int n_playout, int 
         const size_t scratch = az_nn_model_scratch_bytes(model, static_cast<int64_t>(total));
         const int64_t extra = static_cast<int64_t>(n_playout) * m->geo.actions;
         const bool grows = total > m->vl_leaf.slot.n || total > m->ev_rows.n || scratch > m->ev_scratch.n ||
-                           m->used_bound + extra > m->S || (use_table && m->tt_keys.n < 2 * total);
+                           m->room_needs_device(extra) || (use_table && m->tt_keys.n < 2 * total);
         // anything below that allocates, frees or reads a buffer the stream's kernels use waits for them first
         if (grows) HIP_OK(hipStreamSynchronize(s));
         dev_prepare(m, K, n_playout, s, false);
@@ -1187,7 +1241,8 @@ int az_mcts_dev_prune_roots(az_mcts *m, const int32_t *actions, void *stream)
 {
     return guarded([&] {
         hipStream_t s = static_cast<hipStream_t>(stream);
-        az::launch_prune(m->game, m->arena(), m->params(), actions, nullptr, true, s, m->replay_noise);
+        HIP_OK(hipSetDevice(m->device));
+        m->prune_on(actions, nullptr, true, m->replay_noise, s);
         az::launch_bump_call(m->call_ctr.p, s);
     });
 }

@@ -36,11 +36,12 @@ struct SearchParams {
 };
 
 struct TreeArena {
-    HotRec  *hot;
+    HotRec  *hot;    // [B][2][S]: two halves per tree (tree_layout.h)
     ColdRec *cold;
-    int32_t *root;   // [B] slot of each tree's root
-    int32_t *used;   // [B] slots in use
-    int64_t  S;      // slots per tree
+    uint8_t *half;   // [B] the half a tree lives in now
+    int32_t *root;   // [B] slot of each tree's root, relative to its half
+    int32_t *used;   // [B] slots in use in that half
+    int64_t  S;      // slots per half
     int      B;      // trees
 };
 
@@ -121,8 +122,10 @@ void launch_export(int game, LeafBuf lf, SearchParams p, int n_leaves, bool gen_
                    uint8_t *valid_mask, float *features, hipStream_t s);
 // dev_noise: fresh root noise is written by the launch itself - from the device generator, or from
 // `replay_noise` ([B, A] by edge index) when that is given
+// The kept subtree moves into the tree's other half (compaction); max_live: device int that receives,
+// by atomic max, the number of records a tree occupies afterwards; err: the engine's error word.
 void launch_prune(int game, TreeArena ar, SearchParams p, const int32_t *actions, int32_t *noise_req,
-                  bool dev_noise, hipStream_t s, const float *replay_noise = nullptr);
+                  bool dev_noise, hipStream_t s, const float *replay_noise, int *max_live, int *err);
 void launch_apply_noise(int game, TreeArena ar, const int32_t *noise_req, const float *noise, hipStream_t s);
 void launch_reset_masked(TreeArena ar, const uint8_t *mask, hipStream_t s);
 void launch_counts(int game, TreeArena ar, int32_t *counts, hipStream_t s);

@@ -112,6 +112,13 @@ __device__ __forceinline__ HotRec group_bcast(const HotRec &c, int src)
     return r;
 }
 
+// first record of tree t's arena: the half it lives in now (tree_layout.h: two halves per tree, a
+// re-rooting copies the kept subtree into the other one)
+__device__ __forceinline__ size_t tree_base(const TreeArena &ar, int t)
+{
+    return (static_cast<size_t>(t) * 2 + ar.half[t]) * static_cast<size_t>(ar.S);
+}
+
 __device__ __forceinline__ HotRec empty_rec()
 {
     HotRec c;
@@ -167,8 +174,8 @@ __global__ void __launch_bounds__(WAVE) k_select(TreeArena ar, RootState rs, Lea
     const int t = live ? tree : 0;
     const float tree_ne = p.noise_eps_tree != nullptr ? p.noise_eps_tree[t] : p.noise_eps;   // root-noise epsilon of this tree
 
-    HotRec *hot = ar.hot + static_cast<size_t>(t) * ar.S;
-    const ColdRec *cold = ar.cold + static_cast<size_t>(t) * ar.S;
+    HotRec *hot = ar.hot + tree_base(ar, t);
+    const ColdRec *cold = ar.cold + tree_base(ar, t);
     const int root = ar.root[t];
     HotRec rootrec = hot[root];
     int root_infl = rootrec.n_inflight;
@@ -366,8 +373,8 @@ __global__ void __launch_bounds__(WAVE) k_select_staggered(TreeArena ar, RootSta
     const int t = live ? tree : 0;
     const float tree_ne = p.noise_eps_tree != nullptr ? p.noise_eps_tree[t] : p.noise_eps;
 
-    HotRec *hot = ar.hot + static_cast<size_t>(t) * ar.S;
-    const ColdRec *cold = ar.cold + static_cast<size_t>(t) * ar.S;
+    HotRec *hot = ar.hot + tree_base(ar, t);
+    const ColdRec *cold = ar.cold + tree_base(ar, t);
     const int root = ar.root[t];
     HotRec rootrec = hot[root];
     int root_infl = rootrec.n_inflight;
@@ -635,8 +642,8 @@ __global__ void __launch_bounds__(WAVE) k_select8(TreeArena ar, RootState rs, Le
     const float ne = p.noise_eps_tree != nullptr ? p.noise_eps_tree[t] : p.noise_eps;
     const bool root_mix = ne > 0.0f;
 
-    HotRec *hot = ar.hot + static_cast<size_t>(t) * ar.S;
-    const ColdRec *cold = ar.cold + static_cast<size_t>(t) * ar.S;
+    HotRec *hot = ar.hot + tree_base(ar, t);
+    const ColdRec *cold = ar.cold + tree_base(ar, t);
     const int root = ar.root[t];
     HotRec rootrec = hot[root];
     int root_infl = rootrec.n_inflight;
@@ -828,8 +835,8 @@ __global__ void __launch_bounds__(WAVE) k_select8x4(TreeArena ar, RootState rs, 
     const float ne = p.noise_eps_tree != nullptr ? p.noise_eps_tree[t] : p.noise_eps;
     const bool root_mix = ne > 0.0f;
 
-    HotRec *hot = ar.hot + static_cast<size_t>(t) * ar.S;
-    const ColdRec *cold = ar.cold + static_cast<size_t>(t) * ar.S;
+    HotRec *hot = ar.hot + tree_base(ar, t);
+    const ColdRec *cold = ar.cold + tree_base(ar, t);
     const int root = ar.root[t];
     const HotRec rootrec = hot[root];
     GameState st;
@@ -1005,7 +1012,7 @@ __global__ void __launch_bounds__(WAVE) k_remove_vl(TreeArena ar, LeafBuf lf, Se
     const int sub = threadIdx.x % L;
     const int tree = blockIdx.x * (WAVE / L) + threadIdx.x / L;
     if (tree >= ar.B) return;
-    remove_vl_of_tree<G>(ar.hot + static_cast<size_t>(tree) * ar.S, lf, static_cast<size_t>(tree) * strideK, K,
+    remove_vl_of_tree<G>(ar.hot + tree_base(ar, tree), lf, static_cast<size_t>(tree) * strideK, K,
                          p.vl_count, sub);
 }
 
@@ -1027,8 +1034,8 @@ __global__ void __launch_bounds__(WAVE) k_backprop(TreeArena ar, LeafBuf lf, Sea
     const int tree = blockIdx.x * tpw + grp;
     const bool live = grp < tpw && tree < ar.B;
     const int t = live ? tree : 0;
-    HotRec *hot = ar.hot + static_cast<size_t>(t) * ar.S;
-    ColdRec *cold = ar.cold + static_cast<size_t>(t) * ar.S;
+    HotRec *hot = ar.hot + tree_base(ar, t);
+    ColdRec *cold = ar.cold + tree_base(ar, t);
     const size_t flat0 = static_cast<size_t>(t) * K;
     unsigned n_exp = 0, n_dup = 0, n_backup = 0;
 
@@ -1183,8 +1190,8 @@ __global__ void __launch_bounds__(WAVE) k_backprop_batched(TreeArena ar, LeafBuf
     const int tree = blockIdx.x * tpw + grp;
     const bool live = grp < tpw && tree < ar.B;
     const int t = live ? tree : 0;
-    HotRec *hot = ar.hot + static_cast<size_t>(t) * ar.S;
-    ColdRec *cold = ar.cold + static_cast<size_t>(t) * ar.S;
+    HotRec *hot = ar.hot + tree_base(ar, t);
+    ColdRec *cold = ar.cold + tree_base(ar, t);
     const size_t flat0 = static_cast<size_t>(t) * K;
     unsigned n_exp = 0, n_dup = 0, n_backup = 0;
 
@@ -1454,7 +1461,7 @@ __global__ void __launch_bounds__(256) k_init_trees(TreeArena ar)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ar.B) return;
-    write_fresh_root(ar.hot + static_cast<size_t>(t) * ar.S, ar.cold + static_cast<size_t>(t) * ar.S);
+    write_fresh_root(ar.hot + tree_base(ar, t), ar.cold + tree_base(ar, t));
     ar.root[t] = 0;
     ar.used[t] = 1;
 }
@@ -1463,7 +1470,7 @@ __global__ void __launch_bounds__(256) k_reset_masked(TreeArena ar, const uint8_
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ar.B || !mask[t]) return;
-    write_fresh_root(ar.hot + static_cast<size_t>(t) * ar.S, ar.cold + static_cast<size_t>(t) * ar.S);
+    write_fresh_root(ar.hot + tree_base(ar, t), ar.cold + tree_base(ar, t));
     ar.root[t] = 0;
     ar.used[t] = 1;
 }
@@ -1477,63 +1484,118 @@ __device__ __forceinline__ unsigned long long group_ballot(bool pred, int lane)
     return (bal >> (lane - lane % L)) & mask;
 }
 
-// MCTS.h:90-132: re-root at the child reached by `action` if the reference would have
-// allocated it, else reset.  noise_req[t] = number of root edges that need fresh Dirichlet
-// noise (0 if none) for the host generator; with dev_noise the noise is drawn here.
+// MCTS.h:90-132: re-root at the child reached by `action` if the reference would have allocated it,
+// else reset.  The reference keeps the whole old tree in its pools until the next reset
+// (MCTS.h:100-101: only `root_idx` moves); here the KEPT SUBTREE IS COPIED into the tree's other
+// arena half, breadth first, and the tree continues there: what a tree occupies is what is
+// reachable from its root (node numbering is not observable through the API; the order of records
+// inside a sibling block - the edge order - is kept).  One wavefront per tree: a pass takes the
+// records appended by the previous pass (64 at a time), a wave-wide prefix sum of their edge counts
+// places their child blocks behind what is there, every lane copies its node's block.  Stores of a
+// pass are read by other lanes of the same wavefront in the next one (wavefront-scope order, as in
+// k_select8x4; the fence also drains the stores).  noise_req[t] = number of root edges that need
+// fresh Dirichlet noise (host generator); with dev_noise the noise is written here, from the device
+// generator or from `replay_noise`.  max_live: running maximum of the records a tree occupies now.
 template <class G>
 __global__ void __launch_bounds__(WAVE) k_prune(TreeArena ar, SearchParams p, const int32_t *actions,
-                                                int32_t *noise_req, int dev_noise, const float *replay_noise)
+                                                int32_t *noise_req, int dev_noise, const float *replay_noise,
+                                                int *max_live, int *err)
 {
-    constexpr int L = G::LANES;
     const int lane = threadIdx.x;
-    const int sub = lane % L;
-    const int tree = blockIdx.x * (WAVE / L) + lane / L;
-    const bool live = tree < ar.B;
-    const int t = live ? tree : 0;
-    HotRec *hot = ar.hot + static_cast<size_t>(t) * ar.S;
-    ColdRec *cold = ar.cold + static_cast<size_t>(t) * ar.S;
+    const int t = blockIdx.x;
+    const int S = static_cast<int>(ar.S);
+    const int h = ar.half[t];
+    HotRec *hot = ar.hot + (static_cast<size_t>(t) * 2 + h) * ar.S;
+    ColdRec *cold = ar.cold + (static_cast<size_t>(t) * 2 + h) * ar.S;
+    HotRec *nhot = ar.hot + (static_cast<size_t>(t) * 2 + (1 - h)) * ar.S;
+    ColdRec *ncold = ar.cold + (static_cast<size_t>(t) * 2 + (1 - h)) * ar.S;
     const int root = ar.root[t];
     const HotRec R = hot[root];
     const int action = actions[t];
-    const int E = static_cast<int>((R.meta & META_NEDGE_MASK) >> META_NEDGE_SHIFT);
+    const int E = (R.meta & META_EXPANDED) ? static_cast<int>((R.meta & META_NEDGE_MASK) >> META_NEDGE_SHIFT) : 0;
     HotRec c = empty_rec();
     bool match = false;
-    if (live && (R.meta & META_EXPANDED) && sub < E) {
-        c = hot[R.child_off + sub];
+    if (lane < E) {
+        c = hot[R.child_off + lane];
         match = static_cast<int>(c.meta & META_ACTION_MASK) == action && (c.meta & META_EXISTS);
     }
-    const unsigned long long grpb = group_ballot<L>(match, lane);
-    if (!live) return;
-    if (grpb) {
-        const int e = __ffsll(grpb) - 1;
-        const int new_root = R.child_off + e;
-        const uint32_t nm = static_cast<uint32_t>(__shfl(static_cast<int>(c.meta), e, L));
-        const int noff = __shfl(c.child_off, e, L);
-        const int nE = (nm & META_EXPANDED) ? static_cast<int>((nm & META_NEDGE_MASK) >> META_NEDGE_SHIFT) : 0;
-        if (sub == 0) { ar.root[t] = new_root; cold[new_root].parent = -1; }
-        const int want = (p.alpha > 0.0f) ? nE : 0;                  // apply_root_noise
-        if (!dev_noise) {
-            if (sub == 0) noise_req[t] = want;
-        } else if (want > 0 && replay_noise != nullptr) {
-            // recorded draws instead of the generator (az_mcts_dev_replay): row t, edge order
-            if (sub < want) cold[noff + sub].noise = replay_noise[static_cast<size_t>(t) * G::ACTIONS + sub];
-        } else if (want > 0) {
-            float g = 0.0f;
-            if (sub < want) {
-                DevRng rng(p.seed, *p.call_ptr, static_cast<uint64_t>(t), static_cast<uint64_t>(sub) + 128);
-                g = rng.gamma(p.alpha);
-            }
-            float sum = 0.0f;
-            for (int i = 0; i < want; ++i) sum += __shfl(g, i, L);
-            if (sub < want) cold[noff + sub].noise = g * (1.0f / (sum + 1e-8f));
-        }
-    } else {
-        if (sub == 0) {
+    const unsigned long long mb = __ballot(match);
+    if (!mb) {                                                         // MCTS.h:107: reset()
+        if (lane == 0) {
             write_fresh_root(hot, cold);
             ar.root[t] = 0;
             ar.used[t] = 1;
             if (!dev_noise) noise_req[t] = 0;
+            atomicMax(max_live, 1);
         }
+        return;
+    }
+    const int e = __ffsll(mb) - 1;
+    const int old_root = R.child_off + e;
+    if (lane == 0) {
+        nhot[0] = hot[old_root];
+        ColdRec cr = cold[old_root];
+        cr.parent = -1;                                                // MCTS.h:100-101
+        ncold[0] = cr;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    int lo = 0, hi = 1, used = 1;
+    bool overflow = false;
+    while (lo < hi && !overflow) {
+        for (int q0 = lo; q0 < hi; q0 += WAVE) {
+            const int q = q0 + lane;
+            const bool valid = q < hi;
+            HotRec rec = empty_rec();
+            if (valid) rec = nhot[q];                                  // still points at its OLD child block
+            const int nE = (valid && (rec.meta & META_EXPANDED)) ? static_cast<int>((rec.meta & META_NEDGE_MASK) >> META_NEDGE_SHIFT) : 0;
+            int incl = nE;
+#pragma unroll
+            for (int o = 1; o < WAVE; o <<= 1) {
+                const int v = __shfl_up(incl, o, WAVE);
+                if (lane >= o) incl += v;
+            }
+            const int total = __shfl(incl, WAVE - 1, WAVE);
+            if (used + total > S) { overflow = true; break; }         // cannot happen: the subtree fitted in one half before
+            if (nE > 0) {
+                const int dst = used + incl - nE;
+                nhot[q].child_off = dst;
+                for (int j = 0; j < nE; ++j) {
+                    nhot[dst + j] = hot[rec.child_off + j];
+                    ColdRec y = cold[rec.child_off + j];
+                    y.parent = q;
+                    ncold[dst + j] = y;
+                }
+            }
+            used += total;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        lo = hi; hi = used;
+    }
+    if (overflow && lane == 0) atomicOr(err, ERR_ARENA_OVERFLOW);
+    const HotRec NR = nhot[0];
+    const int nE = (NR.meta & META_EXPANDED) ? static_cast<int>((NR.meta & META_NEDGE_MASK) >> META_NEDGE_SHIFT) : 0;
+    const int noff = NR.child_off;
+    if (lane == 0) {
+        ar.half[t] = static_cast<uint8_t>(1 - h);
+        ar.root[t] = 0;
+        ar.used[t] = used;
+        atomicMax(max_live, used);
+    }
+    const int want = (p.alpha > 0.0f) ? nE : 0;                        // apply_root_noise, MCTS.h:113-132
+    if (!dev_noise) {
+        if (lane == 0) noise_req[t] = want;
+    } else if (want > 0 && replay_noise != nullptr) {
+        // recorded draws instead of the generator (az_mcts_dev_replay): row t, edge order
+        if (lane < want) ncold[noff + lane].noise = replay_noise[static_cast<size_t>(t) * G::ACTIONS + lane];
+    } else if (want > 0) {
+        float g = 0.0f;
+        if (lane < want) {
+            DevRng rng(p.seed, *p.call_ptr, static_cast<uint64_t>(t), static_cast<uint64_t>(lane) + 128);
+            g = rng.gamma(p.alpha);
+        }
+        float sum = 0.0f;
+        for (int i = 0; i < want; ++i) sum += __shfl(g, i, WAVE);
+        if (lane < want) ncold[noff + lane].noise = g * (1.0f / (sum + 1e-8f));
     }
 }
 
@@ -1546,8 +1608,8 @@ __global__ void __launch_bounds__(WAVE) k_apply_noise(TreeArena ar, const int32_
     if (tree >= ar.B) return;
     const int nv = noise_req[tree];
     if (nv <= 0 || sub >= nv) return;
-    const HotRec *hot = ar.hot + static_cast<size_t>(tree) * ar.S;
-    ColdRec *cold = ar.cold + static_cast<size_t>(tree) * ar.S;
+    const HotRec *hot = ar.hot + tree_base(ar, tree);
+    ColdRec *cold = ar.cold + tree_base(ar, tree);
     const int off = hot[ar.root[tree]].child_off;
     cold[off + sub].noise = noise[static_cast<size_t>(tree) * G::ACTIONS + sub];
 }
@@ -1567,8 +1629,8 @@ __global__ void __launch_bounds__(WAVE) k_root_query(TreeArena ar, int32_t *coun
     const int tree = blockIdx.x * (WAVE / L) + lane / L;
     const bool live = tree < ar.B;
     const int t = live ? tree : 0;
-    const HotRec *hot = ar.hot + static_cast<size_t>(t) * ar.S;
-    const ColdRec *cold = ar.cold + static_cast<size_t>(t) * ar.S;
+    const HotRec *hot = ar.hot + tree_base(ar, t);
+    const ColdRec *cold = ar.cold + tree_base(ar, t);
     const int root = ar.root[t];
     const HotRec R = hot[root];
     const bool expanded = (R.meta & META_EXPANDED) != 0;
@@ -1842,10 +1904,10 @@ void launch_export(int game, LeafBuf lf, SearchParams p, int n_leaves, bool gen_
 }
 
 void launch_prune(int game, TreeArena ar, SearchParams p, const int32_t *actions, int32_t *noise_req,
-                  bool dev_noise, hipStream_t s, const float *replay_noise)
+                  bool dev_noise, hipStream_t s, const float *replay_noise, int *max_live, int *err)
 {
-    AZ_DISPATCH(game, hipLaunchKernelGGL(k_prune<G>, dim3(grid_for(ar.B, WAVE / G::LANES)), dim3(WAVE), 0, s, ar, p,
-                                         actions, noise_req, dev_noise ? 1 : 0, replay_noise));
+    AZ_DISPATCH(game, hipLaunchKernelGGL(k_prune<G>, dim3(static_cast<unsigned>(ar.B)), dim3(WAVE), 0, s, ar, p,
+                                         actions, noise_req, dev_noise ? 1 : 0, replay_noise, max_live, err));
 }
 
 void launch_apply_noise(int game, TreeArena ar, const int32_t *noise_req, const float *noise, hipStream_t s)

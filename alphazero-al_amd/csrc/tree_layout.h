@@ -12,9 +12,14 @@
 //   hot[tree*S + slot]   32 B  everything selection reads
 //   cold[tree*S + slot]  16 B  what only backup / root queries / root noise read
 //
-// A tree owns slots [0, used) of its arena of S records; slot 0 is the record of a freshly
-// reset root (it has no parent block).  After a prune the root is a record inside its old
-// parent's block; parent == -1 marks it (MCTS.h:100-101).
+// A tree's arena is TWO HALVES of S records, and the tree lives in one of them at a time, in slots
+// [0, used); slot 0 is its root (a freshly reset root, or the root a re-rooting put there; it has
+// no parent block; parent == -1 marks it, MCTS.h:100-101).  The reference never reclaims a node
+// before the next reset (MCTS.h:90-108: its pools only grow), so over a game a tree's pool holds
+// every node ever expanded - n_playout x actions x plies records in the worst case.  Here a
+// re-rooting (k_prune) copies the subtree it keeps into the other half, breadth first, and flips
+// the tree over: a tree occupies what is reachable from its root, and S is sized for one ply's
+// growth on top of that instead of for a whole game.
 #pragma once
 
 #include <cstdint>

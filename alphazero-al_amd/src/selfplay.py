@@ -83,13 +83,15 @@ class DeviceSelfPlay:
         # running totals kept on the device: positions, games, p1 wins, p2 wins, draws
         self.totals = torch.zeros(5, dtype=torch.int64, **z)
         if reserve_slots is None:
-            # The engine never compacts a tree during a game (re-rooting keeps the subtree where it is), so
-            # a tree can need n_playout * actions records per ply of the longest game.  Reserve that much
-            # when it fits in half of the free HBM: growing the arena later means a device-wide stop and
-            # a copy of every tree (measured at n_playout 800: 45 % of the throughput while it happens).
-            worst = self.n_playout * self.search.action_size * self.MAX_PLIES
+            # A re-rooting copies the kept subtree into the tree's other arena half (k_prune), so a tree
+            # occupies what is reachable from its root: the carried subtree plus one ply's growth of at
+            # most n_playout * actions records, not a whole game's worth.  Reserve four plies' growth per
+            # half (measured: the largest tree of 8192 games stays below two); the engine checks the bound
+            # every ply from the occupancy the prune kernel reports and grows the arenas if a tree ever
+            # needs more (a device-wide stop and a copy: rare by construction).
+            want = 4 * self.n_playout * self.search.action_size
             free_bytes, _ = torch.cuda.mem_get_info(dev)
-            reserve_slots = min(worst, int(free_bytes // 2) // (self.B * 48))
+            reserve_slots = min(want, int(free_bytes // 2) // (self.B * 2 * 48))
         if reserve_slots and int(reserve_slots) > 4096:
             F.check(F.lib().az_mcts_reserve(self.h, int(reserve_slots)))
         assert sampler in ("device", "reference")
