@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -161,6 +162,7 @@ struct az_mcts {
     int64_t prune_seq = 0;
     int64_t ring_seq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t growth_after[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t last_extra = 0;   // room asked for by the last search (one ply's worst-case growth)
     int64_t epoch = 0;        // bumped whenever a buffer the dev_* kernels address moves
 
     // roots of the current call
@@ -342,6 +344,7 @@ struct az_mcts {
         }
         used_bound += extra;
         for (auto &g : growth_after) g += extra;
+        last_extra = extra;
     }
 
     void check_device_error()
@@ -373,7 +376,12 @@ struct az_mcts {
         ring_seq[q % 8] = q;
         growth_after[q % 8] = 0;
         HIP_OK(hipMemsetAsync(max_live.p, 0, sizeof(int), s));
-        az::launch_prune(game, arena(), params(), actions_dev, noise_req, dev_noise, s, noise_replay, max_live.p, err.p);
+        // compact the trees that could not take two more plies' worth of growth where they are
+        // (AZ_COMPACT_ALWAYS=1: every tree at every re-rooting)
+        static const bool always = getenv("AZ_COMPACT_ALWAYS") != nullptr && getenv("AZ_COMPACT_ALWAYS")[0] == '1';
+        const int64_t above = always ? 0 : std::max<int64_t>(S / 8, S - 2 * std::max<int64_t>(last_extra, geo.actions));
+        az::launch_prune(game, arena(), params(), actions_dev, noise_req, dev_noise, s, noise_replay, max_live.p, err.p,
+                         static_cast<int>(above));
         HIP_OK(hipMemcpyAsync(const_cast<int *>(&live_ring[q % 8]), max_live.p, sizeof(int), hipMemcpyDeviceToHost, s));
     }
     ~az_mcts()

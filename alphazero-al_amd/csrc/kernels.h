@@ -122,10 +122,11 @@ void launch_export(int game, LeafBuf lf, SearchParams p, int n_leaves, bool gen_
                    uint8_t *valid_mask, float *features, hipStream_t s);
 // dev_noise: fresh root noise is written by the launch itself - from the device generator, or from
 // `replay_noise` ([B, A] by edge index) when that is given
-// The kept subtree moves into the tree's other half (compaction); max_live: device int that receives,
-// by atomic max, the number of records a tree occupies afterwards; err: the engine's error word.
+// A tree that occupies more than `compact_above` records has its kept subtree moved into its other half
+// (compaction), the others re-root in place; max_live: device int that receives, by atomic max, the number
+// of records a tree occupies afterwards; err: the engine's error word.
 void launch_prune(int game, TreeArena ar, SearchParams p, const int32_t *actions, int32_t *noise_req,
-                  bool dev_noise, hipStream_t s, const float *replay_noise, int *max_live, int *err);
+                  bool dev_noise, hipStream_t s, const float *replay_noise, int *max_live, int *err, int compact_above);
 void launch_apply_noise(int game, TreeArena ar, const int32_t *noise_req, const float *noise, hipStream_t s);
 void launch_reset_masked(TreeArena ar, const uint8_t *mask, hipStream_t s);
 void launch_counts(int game, TreeArena ar, int32_t *counts, hipStream_t s);

@@ -1499,7 +1499,7 @@ __device__ __forceinline__ unsigned long long group_ballot(bool pred, int lane)
 template <class G>
 __global__ void __launch_bounds__(WAVE) k_prune(TreeArena ar, SearchParams p, const int32_t *actions,
                                                 int32_t *noise_req, int dev_noise, const float *replay_noise,
-                                                int *max_live, int *err)
+                                                int *max_live, int *err, int compact_above)
 {
     const int lane = threadIdx.x;
     const int t = blockIdx.x;
@@ -1532,6 +1532,35 @@ __global__ void __launch_bounds__(WAVE) k_prune(TreeArena ar, SearchParams p, co
     }
     const int e = __ffsll(mb) - 1;
     const int old_root = R.child_off + e;
+    // A tree that still has room for the plies to come stays where it is - the root moves to the chosen
+    // record, as in the reference (MCTS.h:100-101) - and only a tree past `compact_above` records pays
+    // for the copy: every few plies instead of every ply.
+    if (ar.used[t] <= compact_above) {
+        const uint32_t nm = static_cast<uint32_t>(__shfl(static_cast<int>(c.meta), e, WAVE));
+        const int noff0 = __shfl(c.child_off, e, WAVE);
+        const int nE0 = (nm & META_EXPANDED) ? static_cast<int>((nm & META_NEDGE_MASK) >> META_NEDGE_SHIFT) : 0;
+        if (lane == 0) {
+            ar.root[t] = old_root;
+            cold[old_root].parent = -1;
+            atomicMax(max_live, ar.used[t]);
+        }
+        const int want0 = (p.alpha > 0.0f) ? nE0 : 0;                   // apply_root_noise, MCTS.h:113-132
+        if (!dev_noise) {
+            if (lane == 0) noise_req[t] = want0;
+        } else if (want0 > 0 && replay_noise != nullptr) {
+            if (lane < want0) cold[noff0 + lane].noise = replay_noise[static_cast<size_t>(t) * G::ACTIONS + lane];
+        } else if (want0 > 0) {
+            float g = 0.0f;
+            if (lane < want0) {
+                DevRng rng(p.seed, *p.call_ptr, static_cast<uint64_t>(t), static_cast<uint64_t>(lane) + 128);
+                g = rng.gamma(p.alpha);
+            }
+            float sum = 0.0f;
+            for (int i = 0; i < want0; ++i) sum += __shfl(g, i, WAVE);
+            if (lane < want0) cold[noff0 + lane].noise = g * (1.0f / (sum + 1e-8f));
+        }
+        return;
+    }
     if (lane == 0) {
         nhot[0] = hot[old_root];
         ColdRec cr = cold[old_root];
@@ -1904,10 +1933,10 @@ void launch_export(int game, LeafBuf lf, SearchParams p, int n_leaves, bool gen_
 }
 
 void launch_prune(int game, TreeArena ar, SearchParams p, const int32_t *actions, int32_t *noise_req,
-                  bool dev_noise, hipStream_t s, const float *replay_noise, int *max_live, int *err)
+                  bool dev_noise, hipStream_t s, const float *replay_noise, int *max_live, int *err, int compact_above)
 {
     AZ_DISPATCH(game, hipLaunchKernelGGL(k_prune<G>, dim3(static_cast<unsigned>(ar.B)), dim3(WAVE), 0, s, ar, p,
-                                         actions, noise_req, dev_noise ? 1 : 0, replay_noise, max_live, err));
+                                         actions, noise_req, dev_noise ? 1 : 0, replay_noise, max_live, err, compact_above));
 }
 
 void launch_apply_noise(int game, TreeArena ar, const int32_t *noise_req, const float *noise, hipStream_t s)

@@ -85,11 +85,11 @@ class DeviceSelfPlay:
         if reserve_slots is None:
             # A re-rooting copies the kept subtree into the tree's other arena half (k_prune), so a tree
             # occupies what is reachable from its root: the carried subtree plus one ply's growth of at
-            # most n_playout * actions records, not a whole game's worth.  Reserve four plies' growth per
-            # half (measured: the largest tree of 8192 games stays below two); the engine checks the bound
-            # every ply from the occupancy the prune kernel reports and grows the arenas if a tree ever
-            # needs more (a device-wide stop and a copy: rare by construction).
-            want = 4 * self.n_playout * self.search.action_size
+            # most n_playout * actions records, not a whole game's worth.  Reserve six plies' worst-case
+            # growth per half: a tree is compacted once it could not take two more plies where it is, i.e.
+            # every few plies; the engine checks the bound every ply from the occupancy the prune kernel
+            # reports and grows the arenas if a tree ever needs more (a device-wide stop and a copy).
+            want = 6 * self.n_playout * self.search.action_size
             free_bytes, _ = torch.cuda.mem_get_info(dev)
             reserve_slots = min(want, int(free_bytes // 2) // (self.B * 2 * 48))
         if reserve_slots and int(reserve_slots) > 4096:
