@@ -188,7 +188,7 @@ struct az_mcts {
     int64_t replay_stride = 0, replay_calls = 0, replay_next = 0;
     const float *replay_noise = nullptr;
     // device transposition table of evaluator outputs (tt_kernels.hip)
-    DevBuf<az::TtEntry> tt_entries;
+    DevBuf<uint8_t> tt_entries;     // 2^n entries of az::tt_entry_bytes(game) bytes
     DevBuf<unsigned long long> tt_stats;
     DevBuf<uint64_t> tt_keys;
     uint64_t tt_mask = 0;
@@ -1119,20 +1119,19 @@ int az_mcts_dev_search(az_mcts *m, const az_nn_model *model, int n_playout, int 
 int az_mcts_dev_tt_create(az_mcts *m, int log2_entries)
 {
     return guarded([&] {
-        require(m->game == AZ_GAME_CONNECT4, "dev_tt_create: the transposition table is built for Connect4 only");
         require(log2_entries >= 2 && log2_entries <= 28, "dev_tt_create: log2_entries must be in [2, 28]");
         HIP_OK(hipSetDevice(m->device));
         HIP_OK(hipDeviceSynchronize());
-        const size_t n = static_cast<size_t>(1) << log2_entries;
+        const size_t n = (static_cast<size_t>(1) << log2_entries) * az::tt_entry_bytes(m->game);
         if (n != m->tt_entries.n) {
             if (m->tt_entries.p) { HIP_OK(hipFree(m->tt_entries.p)); m->tt_entries.p = nullptr; m->tt_entries.n = 0; }
             m->tt_entries.ensure(n);
             ++m->epoch;
         }
-        HIP_OK(hipMemset(m->tt_entries.p, 0, n * sizeof(az::TtEntry)));
+        HIP_OK(hipMemset(m->tt_entries.p, 0, n));
         m->tt_stats.ensure(4, true);
         HIP_OK(hipMemset(m->tt_stats.p, 0, 4 * sizeof(unsigned long long)));
-        m->tt_mask = n - 1;
+        m->tt_mask = (static_cast<uint64_t>(1) << log2_entries) - 1;
     });
 }
 
@@ -1140,7 +1139,7 @@ int az_mcts_dev_tt_clear(az_mcts *m, void *stream)
 {
     return guarded([&] {
         require(m->tt_entries.p != nullptr, "dev_tt_clear: no table (az_mcts_dev_tt_create)");
-        HIP_OK(hipMemsetAsync(m->tt_entries.p, 0, m->tt_entries.n * sizeof(az::TtEntry), static_cast<hipStream_t>(stream)));
+        HIP_OK(hipMemsetAsync(m->tt_entries.p, 0, m->tt_entries.n, static_cast<hipStream_t>(stream)));
     });
 }
 
@@ -1158,7 +1157,7 @@ int az_mcts_dev_tt_lookup(az_mcts *m, int K, float *probs, float *wdl_rel, float
             ++m->epoch;
         }
         az::TtTable t{m->tt_entries.p, m->tt_mask, m->tt_stats.p};
-        az::launch_tt_lookup(ls.view(), static_cast<int>(total), t, m->call_ctr.p, probs, wdl_rel, moves_left, miss_idx,
+        az::launch_tt_lookup(m->game, ls.view(), static_cast<int>(total), t, m->call_ctr.p, probs, wdl_rel, moves_left, miss_idx,
                              miss_count, m->tt_keys.p, m->err.p, static_cast<hipStream_t>(stream));
     });
 }
@@ -1171,7 +1170,7 @@ int az_mcts_dev_tt_insert(az_mcts *m, int K, const int32_t *miss_idx, const int6
         const size_t total = static_cast<size_t>(m->B) * K;
         require(K >= 1 && m->tt_keys.n >= 2 * total, "dev_tt_insert: call az_mcts_dev_tt_lookup on this selection first");
         az::TtTable t{m->tt_entries.p, m->tt_mask, m->tt_stats.p};
-        az::launch_tt_insert(static_cast<int>(total), t, m->call_ctr.p, miss_idx, miss_count, m->tt_keys.p, probs, wdl_rel,
+        az::launch_tt_insert(m->game, static_cast<int>(total), t, m->call_ctr.p, miss_idx, miss_count, m->tt_keys.p, probs, wdl_rel,
                              moves_left, static_cast<hipStream_t>(stream));
     });
 }
@@ -1182,7 +1181,8 @@ int az_mcts_dev_tt_refresh(az_mcts *m, const az_nn_model *model, void *stream)
         require(m->tt_entries.p != nullptr, "dev_tt_refresh: no table (az_mcts_dev_tt_create)");
         require(model != nullptr, "dev_tt_refresh: no evaluator model");
         const int kind = az_nn_model_kind(model);
-        require(kind == AZ_NN_KIND_CONNECT4_CNN || kind == AZ_NN_KIND_HASH_CONNECT4, "dev_tt_refresh: not a Connect4 evaluator");
+        require(m->game == AZ_GAME_CONNECT4 && (kind == AZ_NN_KIND_CONNECT4_CNN || kind == AZ_NN_KIND_HASH_CONNECT4),
+                "dev_tt_refresh: re-evaluation in place is built for Connect4 (empty an Othello table with az_mcts_dev_tt_clear)");
         HIP_OK(hipSetDevice(m->device));
         hipStream_t s = static_cast<hipStream_t>(stream);
         const int64_t chunk = 16384;

@@ -82,18 +82,15 @@ struct EvalIn {
     const float   *root_noise;
 };
 
-// Device transposition table (tt_kernels.hip): 64-byte entries, buckets of four
-constexpr int TT_VALUES = 11;                       // policy[7], relative wdl[3], moves left
-struct alignas(64) TtEntry {
-    uint64_t k0, k1;                                // key XOR checksum(value)
-    float    v[TT_VALUES];
-    uint32_t stamp;                                 // call counter at the last insert / hit
-};
+// Device transposition table (tt_kernels.hip): entries of tt_entry_bytes(game) bytes - key (two u64 XORed
+// with a checksum of the value), policy[A], relative wdl[3], auxiliary value, a stamp (0 = never written),
+// padded to 64-byte lines: Connect4 64 B, Othello 320 B - in buckets of four
 struct TtTable {
-    TtEntry *e;
+    void *e;
     uint64_t mask;                                  // entries - 1 (entries = power of two >= 4)
     unsigned long long *stats;                      // lookups, hits, inserts, replaced
 };
+size_t tt_entry_bytes(int game);
 
 // bits of the engine's sticky device error word
 constexpr int ERR_ARENA_OVERFLOW = 1;   // an expansion found no room in its tree's arena (it was dropped)
@@ -141,9 +138,9 @@ void launch_game_valid_mask(int game, const uint64_t *bb0, const uint64_t *bb1, 
 
 // err: the engine's sticky error word (ERR_* bits)
 void launch_live_leaves(LeafBuf lf, int n_leaves, int32_t *idx, int64_t *count, int *err, hipStream_t s, bool clear_count = true);
-void launch_tt_lookup(LeafBuf lf, int n_leaves, TtTable t, const uint64_t *clock, float *probs, float *wdl, float *ml,
+void launch_tt_lookup(int game, LeafBuf lf, int n_leaves, TtTable t, const uint64_t *clock, float *probs, float *wdl, float *ml,
                       int32_t *miss_idx, int64_t *miss_count, uint64_t *keys, int *err, hipStream_t s);
-void launch_tt_insert(int n_leaves, TtTable t, const uint64_t *clock, const int32_t *miss_idx, const int64_t *miss_count,
+void launch_tt_insert(int game, int n_leaves, TtTable t, const uint64_t *clock, const int32_t *miss_idx, const int64_t *miss_count,
                       const uint64_t *keys, const float *probs, const float *wdl, const float *ml, hipStream_t s);
 
 // table refresh (MCTS_cpp.py:361-377): entries [e0, e0+n) -> evaluator inputs + compact list; fresh values -> same keys

@@ -42,49 +42,93 @@ __device__ __forceinline__ uint64_t mirror_columns(uint64_t b)       // 7 bits p
     return r;
 }
 
-// the evaluator's view of a leaf: stones of the side to move, stones of the opponent, who moves
-__device__ __forceinline__ void leaf_key(const LeafBuf &lf, int64_t leaf, uint64_t &k0, uint64_t &k1)
+// Othello boards under the symmetries the search draws ({0, 2, 6, 7}, Othello.h:45,312-326): 2 = rotation
+// by 180 degrees (bit i -> 63 - i), 6 = transposition, 7 = anti-transposition (transpose, then rotate)
+__device__ __forceinline__ uint64_t transpose8x8(uint64_t x)
 {
-    uint64_t p1 = lf.bb0[leaf], p2 = lf.bb1[leaf];
-    if (lf.sym[leaf]) { p1 = mirror_columns(p1); p2 = mirror_columns(p2); }
-    const bool first = lf.turn[leaf] > 0;
-    k0 = (first ? p1 : p2) | (first ? (1ull << 63) : 0ull);
-    k1 = (first ? p2 : p1) | (1ull << 62);                           // never zero: an empty entry matches nothing
+    uint64_t t;
+    t = 0x0f0f0f0f00000000ull & (x ^ (x << 28)); x ^= t ^ (t >> 28);
+    t = 0x3333000033330000ull & (x ^ (x << 14)); x ^= t ^ (t >> 14);
+    t = 0x5500550055005500ull & (x ^ (x << 7));  x ^= t ^ (t >> 7);
+    return x;
+}
+__device__ __forceinline__ uint64_t othello_sym(uint64_t b, int sym)
+{
+    if (sym == 2) return __brevll(b);
+    if (sym == 6) return transpose8x8(b);
+    if (sym == 7) return __brevll(transpose8x8(b));
+    return b;
 }
 
-__device__ __forceinline__ uint64_t value_sum(const float *v)
-{
-    uint64_t c = 0x9e3779b97f4a7c15ull;
-#pragma unroll
-    for (int i = 0; i < TT_VALUES; ++i) c = mix64(c ^ __float_as_uint(v[i])) + i;
-    return c;
-}
+// Geometry of a game's table: values = policy[A], relative wdl[3], auxiliary value; an entry is the key
+// (two u64, XORed with a checksum of the value), the values, a stamp, padded to whole 64-byte lines.
+template <class G>
+struct Tt {
+    static constexpr int A = G::ACTIONS;
+    static constexpr int NV = A + 4;
+    static constexpr int BYTES = (16 + 4 * NV + 4 + 63) / 64 * 64;      // Connect4 64, Othello 320
+    __device__ static uint8_t *entry(const TtTable &t, uint64_t i) { return reinterpret_cast<uint8_t *>(t.e) + i * BYTES; }
+    __device__ static uint64_t *key(uint8_t *e) { return reinterpret_cast<uint64_t *>(e); }
+    __device__ static float *val(uint8_t *e) { return reinterpret_cast<float *>(e + 16); }
+    __device__ static uint32_t *stamp(uint8_t *e) { return reinterpret_cast<uint32_t *>(e + 16 + 4 * NV); }
+    __device__ static uint64_t value_sum(const float *v)
+    {
+        uint64_t c = 0x9e3779b97f4a7c15ull;
+        for (int i = 0; i < NV; ++i) c = mix64(c ^ __float_as_uint(v[i])) + i;
+        return c;
+    }
+    // the evaluator's view of a leaf: stones of the side to move, stones of the opponent, who moves
+    __device__ static void leaf_key(const LeafBuf &lf, int64_t leaf, uint64_t &k0, uint64_t &k1)
+    {
+        uint64_t p1 = lf.bb0[leaf], p2 = lf.bb1[leaf];
+        const int sym = lf.sym[leaf];
+        if (G::GAME_ID == 0) {
+            if (sym) { p1 = mirror_columns(p1); p2 = mirror_columns(p2); }
+        } else {
+            p1 = othello_sym(p1, sym); p2 = othello_sym(p2, sym);
+        }
+        const bool first = lf.turn[leaf] > 0;
+        if (G::GAME_ID == 0) {
+            k0 = (first ? p1 : p2) | (first ? (1ull << 63) : 0ull);
+            k1 = (first ? p2 : p1) | (1ull << 62);                       // never zero: an empty entry matches nothing
+        } else {
+            // all 64 bits are squares: the side to move goes into the ORDER of the words, and the stamp word's
+            // neighbour - the values - is what tells an empty entry apart (an empty entry has k0 = k1 = 0 and
+            // stamp 0; a resident one always has a non-zero checksum word, see lookup)
+            k0 = first ? p1 : ~p2;
+            k1 = first ? p2 : ~p1;
+        }
+    }
+};
 
+template <class G>
 __global__ void __launch_bounds__(256) k_tt_lookup(LeafBuf lf, int n_leaves, TtTable t, const uint64_t *clock,
                                                    float *probs, float *wdl, float *ml, int32_t *miss_idx,
                                                    int64_t *miss_count, uint64_t *keys, int *err)
 {
+    using T = Tt<G>;
     const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const bool in = i < n_leaves;
     bool miss = false, hit = false;
     if (in && !(lf.flags[i] & LEAF_TERMINAL)) {           // terminal leaves take their result from the game
         uint64_t k0, k1;
-        leaf_key(lf, i, k0, k1);
+        T::leaf_key(lf, i, k0, k1);
         keys[2 * i] = k0;
         keys[2 * i + 1] = k1;
         const uint64_t bucket = (mix64(k0 ^ mix64(k1)) & t.mask) & ~3ull;
         miss = true;
         for (int j = 0; j < 4 && miss; ++j) {
-            TtEntry e = t.e[bucket + j];
-            const uint64_t c = value_sum(e.v);
-            if ((e.k0 ^ c) == k0 && (e.k1 ^ (c << 17 | c >> 47)) == k1) {
+            uint8_t *e = T::entry(t, bucket + j);
+            if (*T::stamp(e) == 0) continue;              // never written
+            const float *v = T::val(e);
+            const uint64_t c = T::value_sum(v);
+            if ((T::key(e)[0] ^ c) == k0 && (T::key(e)[1] ^ (c << 17 | c >> 47)) == k1) {
                 miss = false;
                 hit = true;
-#pragma unroll
-                for (int a = 0; a < 7; ++a) probs[i * 7 + a] = e.v[a];
-                wdl[i * 3 + 0] = e.v[7]; wdl[i * 3 + 1] = e.v[8]; wdl[i * 3 + 2] = e.v[9];
-                ml[i] = e.v[10];
-                t.e[bucket + j].stamp = static_cast<uint32_t>(*clock);      // recently used
+                for (int a = 0; a < T::A; ++a) probs[i * T::A + a] = v[a];
+                wdl[i * 3 + 0] = v[T::A]; wdl[i * 3 + 1] = v[T::A + 1]; wdl[i * 3 + 2] = v[T::A + 2];
+                ml[i] = v[T::A + 3];
+                *T::stamp(e) = static_cast<uint32_t>(*clock) | 1u;      // recently used (never 0)
             }
         }
     }
@@ -110,37 +154,44 @@ __global__ void __launch_bounds__(256) k_tt_lookup(LeafBuf lf, int n_leaves, TtT
     }
 }
 
+template <class G>
 __global__ void __launch_bounds__(256) k_tt_insert(TtTable t, int n_leaves, const uint64_t *clock, const int32_t *miss_idx,
                                                    const int64_t *miss_count, const uint64_t *keys, const float *probs,
                                                    const float *wdl, const float *ml)
 {
+    using T = Tt<G>;
     const int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (j >= *miss_count || j >= n_leaves) return;
     const int64_t i = miss_idx[j];
     if (i < 0 || i >= n_leaves) return;
     const uint64_t k0 = keys[2 * i], k1 = keys[2 * i + 1];
-    TtEntry e;
-#pragma unroll
-    for (int a = 0; a < 7; ++a) e.v[a] = probs[i * 7 + a];
-    e.v[7] = wdl[i * 3 + 0]; e.v[8] = wdl[i * 3 + 1]; e.v[9] = wdl[i * 3 + 2];
-    e.v[10] = ml[i];
-    const uint64_t c = value_sum(e.v);
-    e.k0 = k0 ^ c;
-    e.k1 = k1 ^ (c << 17 | c >> 47);
-    const uint32_t now = static_cast<uint32_t>(*clock);
-    e.stamp = now;
+    // checksum of the value as it will be stored
+    uint64_t c = 0x9e3779b97f4a7c15ull;
+    for (int a = 0; a < T::NV; ++a) {
+        const float x = a < T::A ? probs[i * T::A + a] : (a < T::A + 3 ? wdl[i * 3 + (a - T::A)] : ml[i]);
+        c = mix64(c ^ __float_as_uint(x)) + a;
+    }
+    const uint64_t e0 = k0 ^ c, e1 = k1 ^ (c << 17 | c >> 47);
+    const uint32_t now = static_cast<uint32_t>(*clock) | 1u;
     const uint64_t bucket = (mix64(k0 ^ mix64(k1)) & t.mask) & ~3ull;
     int victim = 0;
     uint32_t oldest = 0;
     bool replaced = true;
     for (int s = 0; s < 4; ++s) {
-        const TtEntry cur = t.e[bucket + s];
-        if (cur.k0 == e.k0 && cur.k1 == e.k1) { victim = s; replaced = false; break; }      // same key, same value
-        const bool empty = cur.k0 == 0 && cur.k1 == 0;
-        const uint32_t age = empty ? 0xffffffffu : now - cur.stamp;
+        uint8_t *cur = T::entry(t, bucket + s);
+        const uint32_t st = *T::stamp(cur);
+        if (st != 0 && T::key(cur)[0] == e0 && T::key(cur)[1] == e1) { victim = s; replaced = false; break; }   // same key, same value
+        const bool empty = st == 0;
+        const uint32_t age = empty ? 0xffffffffu : now - st;
         if (s == 0 || age > oldest) { oldest = age; victim = s; replaced = !empty; }
     }
-    t.e[bucket + victim] = e;
+    uint8_t *dst = T::entry(t, bucket + victim);
+    T::key(dst)[0] = e0; T::key(dst)[1] = e1;
+    float *v = T::val(dst);
+    for (int a = 0; a < T::A; ++a) v[a] = probs[i * T::A + a];
+    v[T::A] = wdl[i * 3 + 0]; v[T::A + 1] = wdl[i * 3 + 1]; v[T::A + 2] = wdl[i * 3 + 2];
+    v[T::A + 3] = ml[i];
+    *T::stamp(dst) = now;
     atomicAdd(&t.stats[2], 1ull);
     if (replaced) atomicAdd(&t.stats[3], 1ull);
 }
@@ -167,11 +218,12 @@ __global__ void __launch_bounds__(256) k_tt_refresh_gather(TtTable t, uint64_t e
 {
     const int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     bool live = false;
+    using T = Tt<Connect4Dev>;
     if (j < n) {
-        TtEntry e = t.e[e0 + j];
-        if (e.k0 != 0 || e.k1 != 0) {
-            const uint64_t c = value_sum(e.v);
-            const uint64_t k0 = e.k0 ^ c, k1 = e.k1 ^ (c << 17 | c >> 47);
+        uint8_t *ent = T::entry(t, e0 + j);
+        if (*T::stamp(ent) != 0) {
+            const uint64_t c = T::value_sum(T::val(ent));
+            const uint64_t k0 = T::key(ent)[0] ^ c, k1 = T::key(ent)[1] ^ (c << 17 | c >> 47);
             const uint64_t own = k0 & ~(1ull << 63), opp = k1 & ~(1ull << 62);
             if ((k1 >> 62) == 1ull && plausible_c4(own, opp)) {
                 live = true;
@@ -186,8 +238,7 @@ __global__ void __launch_bounds__(256) k_tt_refresh_gather(TtTable t, uint64_t e
                 }
                 for (int a = 0; a < 7; ++a) mask[j * 7 + a] = (((own | opp) >> (a * 7 + 5)) & 1ull) ? 0 : 1;
             } else {
-                TtEntry z{};                                          // unreadable: empty it
-                t.e[e0 + j] = z;
+                *T::stamp(ent) = 0;                                   // unreadable: empty it
             }
         }
     }
@@ -211,16 +262,16 @@ __global__ void __launch_bounds__(256) k_tt_refresh_store(TtTable t, uint64_t e0
     if (q >= *count || q >= n) return;
     const int64_t j = rows[q];
     if (j < 0 || j >= n) return;
-    TtEntry e;
+    using T = Tt<Connect4Dev>;
+    uint8_t *ent = T::entry(t, e0 + j);
+    float *v = T::val(ent);
 #pragma unroll
-    for (int a = 0; a < 7; ++a) e.v[a] = probs[j * 7 + a];
-    e.v[7] = wdl[j * 3 + 0]; e.v[8] = wdl[j * 3 + 1]; e.v[9] = wdl[j * 3 + 2];
-    e.v[10] = ml[j];
-    const uint64_t c = value_sum(e.v);
-    e.k0 = keys[2 * j] ^ c;
-    e.k1 = keys[2 * j + 1] ^ (c << 17 | c >> 47);
-    e.stamp = t.e[e0 + j].stamp;                                      // age is not changed by a refresh
-    t.e[e0 + j] = e;
+    for (int a = 0; a < 7; ++a) v[a] = probs[j * 7 + a];
+    v[7] = wdl[j * 3 + 0]; v[8] = wdl[j * 3 + 1]; v[9] = wdl[j * 3 + 2];
+    v[10] = ml[j];
+    const uint64_t c = T::value_sum(v);
+    T::key(ent)[0] = keys[2 * j] ^ c;
+    T::key(ent)[1] = keys[2 * j + 1] ^ (c << 17 | c >> 47);            // the stamp - its age - is not changed by a refresh
 }
 
 // The leaves an evaluator has to see: everything but terminal leaves, whose value comes from the
@@ -278,19 +329,27 @@ void launch_tt_refresh_store(TtTable t, uint64_t e0, int n, const int32_t *rows,
     hipLaunchKernelGGL(k_tt_refresh_store, dim3((n + 255) / 256), dim3(256), 0, s, t, e0, n, rows, count, keys, probs, wdl, ml);
 }
 
-void launch_tt_lookup(LeafBuf lf, int n_leaves, TtTable t, const uint64_t *clock, float *probs, float *wdl, float *ml,
+size_t tt_entry_bytes(int game) { return game == Connect4Dev::GAME_ID ? Tt<Connect4Dev>::BYTES : Tt<OthelloDev>::BYTES; }
+
+void launch_tt_lookup(int game, LeafBuf lf, int n_leaves, TtTable t, const uint64_t *clock, float *probs, float *wdl, float *ml,
                       int32_t *miss_idx, int64_t *miss_count, uint64_t *keys, int *err, hipStream_t s)
 {
     (void)hipMemsetAsync(miss_count, 0, sizeof(int64_t), s);
-    hipLaunchKernelGGL(k_tt_lookup, dim3((n_leaves + 255) / 256), dim3(256), 0, s, lf, n_leaves, t, clock, probs, wdl, ml,
-                       miss_idx, miss_count, keys, err);
+    const dim3 grid((n_leaves + 255) / 256), block(256);
+    if (game == Connect4Dev::GAME_ID)
+        hipLaunchKernelGGL(k_tt_lookup<Connect4Dev>, grid, block, 0, s, lf, n_leaves, t, clock, probs, wdl, ml, miss_idx, miss_count, keys, err);
+    else
+        hipLaunchKernelGGL(k_tt_lookup<OthelloDev>, grid, block, 0, s, lf, n_leaves, t, clock, probs, wdl, ml, miss_idx, miss_count, keys, err);
 }
 
-void launch_tt_insert(int n_leaves, TtTable t, const uint64_t *clock, const int32_t *miss_idx, const int64_t *miss_count,
+void launch_tt_insert(int game, int n_leaves, TtTable t, const uint64_t *clock, const int32_t *miss_idx, const int64_t *miss_count,
                       const uint64_t *keys, const float *probs, const float *wdl, const float *ml, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_tt_insert, dim3((n_leaves + 255) / 256), dim3(256), 0, s, t, n_leaves, clock, miss_idx, miss_count, keys,
-                       probs, wdl, ml);
+    const dim3 grid((n_leaves + 255) / 256), block(256);
+    if (game == Connect4Dev::GAME_ID)
+        hipLaunchKernelGGL(k_tt_insert<Connect4Dev>, grid, block, 0, s, t, n_leaves, clock, miss_idx, miss_count, keys, probs, wdl, ml);
+    else
+        hipLaunchKernelGGL(k_tt_insert<OthelloDev>, grid, block, 0, s, t, n_leaves, clock, miss_idx, miss_count, keys, probs, wdl, ml);
 }
 
 }  // namespace az

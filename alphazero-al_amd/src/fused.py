@@ -227,11 +227,16 @@ class FusedSearch:
             raise RuntimeError("the device transposition table needs the HIP inference twin of the Connect4 network "
                                "(a module with the reference CNN's parameters on a GPU)")
         check(lib().az_mcts_dev_tt_create(self.h, int(log2_entries)))
+        if getattr(self.fast, "compact_needs_host", False):
+            self.use_graph = False        # the miss list's length is read back on the host: nothing to capture
         self.table_log2 = int(log2_entries)
         self.table_verify = bool(verify)
         self.tt_mismatch = torch.zeros((), dtype=torch.int64, device=self.device)
         self._graphs.clear()
         self._eager_runs.clear()
+
+    def _table_row_width(self):
+        return self.A
 
     def refresh_table(self):
         """`refresh_cache` of the reference's wrapper (MCTS_cpp.py:361-377) for the device table: every
@@ -332,7 +337,8 @@ class FusedSearch:
     def _iteration(self, K, vl):
         if self.table_log2:
             return self._iteration_with_table(K, vl)
-        if self.compact_eval and self.fast is not None and getattr(self.fast, "supports_compact", False):
+        if (self.compact_eval and self.fast is not None and getattr(self.fast, "supports_compact", False)
+                and not (self.use_graph and getattr(self.fast, "compact_needs_host", False))):
             return self._iteration_compact(K, vl)
         L = lib()
         feats, mask = self._buffers(K)

@@ -995,6 +995,27 @@ def test_fast_othello_twin_matches_module(env):
     w.batch_playout(net, boards, turns, vl_batch=4, fused=True)
     assert isinstance(w._fused.fast, FastOthelloNet)
     assert (w.get_visits_count().sum(1) == 39).all()
+    # compact batches: only the rows a device-side list names are evaluated and scattered back - the live
+    # leaves, or what missed the table.  The convolution kernel computes a sample on its own, the thin
+    # library GEMMs of the heads need not be bit-stable across batch sizes: compare within bf16 error.
+    rows = torch.tensor([5, 17, 3, 150, 42], dtype=torch.int32, device="cuda")
+    out = (torch.zeros_like(p1), torch.zeros_like(w1), torch.zeros_like(u1))
+    twin.predict_device(x, m, rows=rows, n_rows=torch.tensor([5], device="cuda"), out=out)
+    idx = rows.long()
+    assert (out[0][idx] - p1[idx]).abs().max().item() < 5e-3 and (out[1][idx] - w1[idx]).abs().max().item() < 5e-3
+    untouched = torch.ones(200, dtype=torch.bool, device="cuda"); untouched[idx] = False
+    assert out[0][untouched].abs().max().item() == 0.0
+    # the device table with the network (the wrapper's cache_size on the fused path): two searches from the same
+    # roots, the second served mostly from the table
+    w = env["W"].BatchedMCTS(200, 1.4, 800, 0.0, 40, noise_epsilon=0.0, fpu_reduction=0.2, use_symmetry=True,
+                             game_name="Othello", score_utility_factor=0.15, score_scale=8.0, cache_size=200000)
+    for rep in range(2):
+        for i in range(200):
+            w.mcts.reset_env(i)
+        w.batch_playout(net, boards, turns, vl_batch=4, fused=True)
+        assert (w.get_visits_count().sum(1) == 39).all()
+    st = w._fused.table_stats()
+    assert w._fused.table_log2 == 18 and st["hits"] > 0.3 * st["lookups"], st
 
 
 def test_native_search_refuses_misuse_and_reservation_is_sized(env):

@@ -253,6 +253,23 @@ def test_table_on_equals_oracle(env):
         assert st["hits"] > 0 and st["inserts"] > 0 and (log2 != 12 or st["replaced"] > 0), st
 
 
+def test_othello_table_on_equals_oracle(env):
+    """The table for Othello (entries of 65 policy values; key = the leaf under the drawn symmetry of
+    {0, 2, 6, 7}, side to move in the order of the two words): native loop, hash evaluator, replayed
+    draws, 96 trees of which 32 share a position - bit-exact against the oracle, with hits."""
+    rng = np.random.default_rng(123)
+    boards, turns = S.ot_openings(rng, 96, 30, 0)
+    boards[:32] = boards[0]; turns[:32] = turns[0]
+    n, K = 60, 4
+    cfg = dict(S.OT_ACTOR_CFG, c_base=5.0 * n)
+    tape = oracle_with_tape(S.OthelloGame, O.BatchedMCTS_Othello, cfg, boards, turns, n, K, 3, seed=17)
+    for log2 in (10, 16):
+        st = {}
+        counts, stats = device_loop_with_tape(env, "Othello", cfg, boards, turns, n, K, 3, tape, True, table_log2=log2, table_stats=st)
+        _compare(tape, counts, stats)
+        assert st["hits"] > 0 and st["inserts"] > 0 and (log2 != 10 or st["replaced"] > 0), st
+
+
 @pytest.mark.parametrize("games,plies", [(2048, 3), (16384, 1)])
 def test_config5_full_size_table_equals_oracle(env, games, plies):
     """BASELINE config 5 at its own sizes - symmetry on, table of 2^20 entries, 2048 games (one
