@@ -1007,7 +1007,7 @@ def test_fast_othello_twin_matches_module(env):
     assert out[0][untouched].abs().max().item() == 0.0
     # the device table with the network (the wrapper's cache_size on the fused path): two searches from the same
     # roots, the second served mostly from the table
-    w = env["W"].BatchedMCTS(200, 1.4, 800, 0.0, 40, noise_epsilon=0.0, fpu_reduction=0.2, use_symmetry=True,
+    w = env["W"].BatchedMCTS(200, 1.4, 800, 0.0, 40, noise_epsilon=0.0, fpu_reduction=0.2, use_symmetry=False,
                              game_name="Othello", score_utility_factor=0.15, score_scale=8.0, cache_size=200000)
     for rep in range(2):
         for i in range(200):
@@ -1015,7 +1015,7 @@ def test_fast_othello_twin_matches_module(env):
         w.batch_playout(net, boards, turns, vl_batch=4, fused=True)
         assert (w.get_visits_count().sum(1) == 39).all()
     st = w._fused.table_stats()
-    assert w._fused.table_log2 == 18 and st["hits"] > 0.3 * st["lookups"], st
+    assert w._fused.table_log2 == 18 and st["hits"] > 0.4 * st["lookups"], st      # the second search replays the first
 
 
 def test_native_search_refuses_misuse_and_reservation_is_sized(env):
