@@ -1012,6 +1012,37 @@ void select_and_gather(az_mcts *m, int K, int vl, float *features, uint8_t *vali
 }
 }  // namespace
 
+namespace {
+// The native loop's form of the same step: selection, then - instead of the gather into feature planes - the
+// leaves' symmetry ids, action masks and (unless the table's lookup builds it) the compact list of leaves to
+// evaluate, for an evaluator that reads the leaf positions themselves (az_nn_model_forward_positions).
+void select_and_prep(az_mcts *m, int K, int vl, uint8_t *valid_mask, int32_t *rows, int64_t *n_rows, void *stream)
+{
+    require(K >= 1 && (vl || K == 1), "dev_select: K must be 1 without virtual loss");
+    LeafStore &ls = vl ? m->vl_leaf : m->plain_leaf;
+    const size_t total = static_cast<size_t>(m->B) * K;
+    require(ls.slot.n >= total && m->tab.p, "dev_select: call az_mcts_dev_prepare first");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (vl) m->vl_stride = K;
+    m->last_select_vl = vl != 0;
+    const az::SearchParams p = m->params();
+    const bool timed = m->profiling && (m->profile_seen[0]++ % m->profile_stride) == 0 && m->ev_select.begin(s);
+    az::launch_select(m->game, m->arena(), m->roots(), ls.view(), p, K, vl != 0, m->counters.p, s, m->call_ctr.p, n_rows);
+    if (timed) m->ev_select.end(s);
+    bool gen_sym = true;
+    if (m->replay_sym != nullptr) {             // recorded symmetry ids instead of the generator's
+        if (m->replay_next >= m->replay_calls || static_cast<int64_t>(total) > m->replay_stride)
+            throw AzError(AZ_ERR_STATE, "dev_select: the replay tape (az_mcts_dev_replay) is exhausted or too narrow");
+        HIP_OK(hipMemcpyAsync(ls.sym.p, m->replay_sym + m->replay_next * m->replay_stride, sizeof(int32_t) * total,
+                              hipMemcpyDeviceToDevice, s));
+        ++m->replay_next;
+        gen_sym = false;
+    }
+    az::launch_leaf_prep(m->game, ls.view(), p, static_cast<int>(total), gen_sym, valid_mask, rows, n_rows, m->err.p, s);
+    ++m->select_launches;
+}
+}  // namespace
+
 int az_mcts_dev_select(az_mcts *m, int K, int vl, float *features, uint8_t *valid_mask, void *stream)
 {
     return guarded([&] { select_and_gather(m, K, vl, features, valid_mask, stream, nullptr); });
@@ -1086,17 +1117,32 @@ int az_mcts_dev_search(az_mcts *m, const az_nn_model *model, int n_playout, int 
         auto ok = [&](int rc, const char *what) {
             if (rc != AZ_OK) throw AzError(AZ_ERR_DEVICE, std::string("dev_search: ") + what + ": " + g_last_error);
         };
+        // AZ_SEARCH_FEATURES=1: the first form of the loop - leaves gathered into feature planes (k_export), the
+        // list from k_live_leaves - kept for A/B runs; default: the evaluator reads the leaf positions
+        static const bool via_features = getenv("AZ_SEARCH_FEATURES") != nullptr && getenv("AZ_SEARCH_FEATURES")[0] == '1';
         auto iteration = [&](int k, int vl) {
             const int64_t n = static_cast<int64_t>(m->B) * k;
-            select_and_gather(m, k, vl, m->ev_feat.p, m->ev_mask.p, stream, use_table ? nullptr : m->ev_nrows.p);
+            LeafStore &ls = vl ? m->vl_leaf : m->plain_leaf;
+            if (via_features) {
+                select_and_gather(m, k, vl, m->ev_feat.p, m->ev_mask.p, stream, use_table ? nullptr : m->ev_nrows.p);
+                if (!use_table)
+                    az::launch_live_leaves(ls.view(), static_cast<int>(n), m->ev_rows.p, m->ev_nrows.p, m->err.p, s, false);
+            } else {
+                // the selection launch clears the count; with the table its lookup builds the list instead
+                select_and_prep(m, k, vl, m->ev_mask.p, use_table ? nullptr : m->ev_rows.p, use_table ? nullptr : m->ev_nrows.p, stream);
+            }
             if (use_table)
                 ok(az_mcts_dev_tt_lookup(m, k, m->ev_probs.p, m->ev_wdl.p, m->ev_ml.p, m->ev_rows.p, m->ev_nrows.p, stream), "tt_lookup");
-            else
-                az::launch_live_leaves((vl ? m->vl_leaf : m->plain_leaf).view(), static_cast<int>(n), m->ev_rows.p, m->ev_nrows.p,
-                                       m->err.p, s, false);   // the selection launch cleared the count
-            if (az_nn_model_forward(model, m->ev_feat.p, m->ev_mask.p, m->ev_probs.p, m->ev_wdl.p, m->ev_ml.p, n,
-                                    m->ev_rows.p, m->ev_nrows.p, m->ev_scratch.p, m->ev_scratch.n, stream) != 0)
-                throw AzError(AZ_ERR_ARG, "dev_search: az_nn_model_forward refused its arguments");
+            int rc;
+            if (via_features) {
+                rc = az_nn_model_forward(model, m->ev_feat.p, m->ev_mask.p, m->ev_probs.p, m->ev_wdl.p, m->ev_ml.p, n,
+                                         m->ev_rows.p, m->ev_nrows.p, m->ev_scratch.p, m->ev_scratch.n, stream);
+            } else {
+                const az_nn_positions pos{ls.bb0.p, ls.bb1.p, ls.turn.p, ls.sym.p};
+                rc = az_nn_model_forward_positions(model, &pos, m->ev_mask.p, m->ev_probs.p, m->ev_wdl.p, m->ev_ml.p, n,
+                                                   m->ev_rows.p, m->ev_nrows.p, m->ev_scratch.p, m->ev_scratch.n, stream);
+            }
+            if (rc != 0) throw AzError(AZ_ERR_ARG, "dev_search: the evaluator model refused its arguments");
             if (use_table)
                 ok(az_mcts_dev_tt_insert(m, k, m->ev_rows.p, m->ev_nrows.p, m->ev_probs.p, m->ev_wdl.p, m->ev_ml.p, stream), "tt_insert");
             ok(az_mcts_dev_backprop(m, k, vl, m->ev_probs.p, m->ev_wdl.p, m->ev_ml.p, stream), "backprop");

@@ -137,6 +137,10 @@ void launch_game_valid_mask(int game, const uint64_t *bb0, const uint64_t *bb1, 
                             uint8_t *mask, int64_t n, hipStream_t s);
 
 // err: the engine's sticky error word (ERR_* bits)
+// symmetry ids + action masks + (idx != nullptr) the compact list of non-terminal leaves, for evaluators that read
+// leaf positions; `count` must have been cleared (the selection launch does)
+void launch_leaf_prep(int game, LeafBuf lf, SearchParams p, int n_leaves, bool gen_sym, uint8_t *valid_mask, int32_t *idx,
+                      int64_t *count, int *err, hipStream_t s);
 void launch_live_leaves(LeafBuf lf, int n_leaves, int32_t *idx, int64_t *count, int *err, hipStream_t s, bool clear_count = true);
 void launch_tt_lookup(int game, LeafBuf lf, int n_leaves, TtTable t, const uint64_t *clock, float *probs, float *wdl, float *ml,
                       int32_t *miss_idx, int64_t *miss_count, uint64_t *keys, int *err, hipStream_t s);

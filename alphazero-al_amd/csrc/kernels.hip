@@ -1445,6 +1445,62 @@ __global__ void __launch_bounds__(256) k_export(LeafBuf lf, SearchParams p, int 
     }
 }
 
+// What the native loop needs between a selection and its evaluator when the evaluator reads leaf POSITIONS
+// (az_nn_model_forward_positions) instead of feature planes: the symmetry id every non-terminal leaf is shown
+// under (BatchedMCTS.h:148-154), its action mask in that frame, and the compact list of the leaves to
+// evaluate (everything but terminal leaves, MCTS_cpp.py:275-297) - k_export's ids and mask and
+// k_live_leaves' list in one pass of one thread per leaf, with no feature tensor written or read.
+template <class G>
+__global__ void __launch_bounds__(1024) k_leaf_prep(LeafBuf lf, SearchParams p, int n_leaves, int gen_sym,
+                                                    uint8_t *valid_mask, int32_t *idx, long long *count, int *err)
+{
+    constexpr int A = G::ACTIONS;
+    __shared__ int s_wave[16];
+    __shared__ long long s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t leaf = static_cast<int64_t>(blockIdx.x) * blockDim.x + tid;
+    bool livel = false;
+    if (leaf < n_leaves) {
+        GameState s;
+        s.bb0 = lf.bb0[leaf]; s.bb1 = lf.bb1[leaf]; s.turn = lf.turn[leaf]; s.aux = lf.aux[leaf];
+        const bool term = (lf.flags[leaf] & LEAF_TERMINAL) != 0;
+        livel = !term;
+        int sym;
+        if (gen_sym) {
+            sym = 0;
+            if (!term && p.use_symmetry) {                         // the draw of k_export, leaf for leaf
+                DevRng g(p.seed, *p.call_ptr, static_cast<uint64_t>(leaf), 7);
+                sym = G::sym_of_choice(static_cast<int>((static_cast<uint64_t>(g.next()) * G::SYM_CHOICES) >> 32));
+            }
+            lf.sym[leaf] = sym;
+        } else {
+            sym = lf.sym[leaf];
+        }
+        if (valid_mask != nullptr)
+            for (int a = 0; a < A; ++a) valid_mask[leaf * A + a] = (!term && G::valid_in_frame(s, sym, a)) ? 1 : 0;
+    }
+    if (idx == nullptr) return;                                    // uniform: the table's lookup builds the list
+    const unsigned long long m = __ballot(livel);
+    if (lane == 0) s_wave[wave] = __popcll(m);
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const int c = s_wave[w];
+        if (w < wave) before += c;
+        total += c;
+    }
+    if (tid == 0)
+        s_base = total ? static_cast<long long>(atomicAdd(reinterpret_cast<unsigned long long *>(count),
+                                                          static_cast<unsigned long long>(total))) : 0;
+    __syncthreads();
+    if (livel) {
+        const long long pos = s_base + before + __popcll(m & ((1ull << lane) - 1));
+        if (pos >= 0 && pos < n_leaves) idx[pos] = static_cast<int32_t>(leaf);
+        else atomicOr(err, ERR_LIST_OVERFLOW);
+    }
+}
+
 // ------------------------------------------------------------------ tree maintenance
 
 __device__ __forceinline__ void write_fresh_root(HotRec *hot, ColdRec *cold)
@@ -1930,6 +1986,13 @@ void launch_export(int game, LeafBuf lf, SearchParams p, int n_leaves, bool gen_
         hipLaunchKernelGGL(k_export<G>, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0, s, lf, p,
                            n_leaves, gen_sym ? 1 : 0, boards, valid_mask, features);
     });
+}
+
+void launch_leaf_prep(int game, LeafBuf lf, SearchParams p, int n_leaves, bool gen_sym, uint8_t *valid_mask, int32_t *idx,
+                      int64_t *count, int *err, hipStream_t s)
+{
+    AZ_DISPATCH(game, hipLaunchKernelGGL(k_leaf_prep<G>, dim3((n_leaves + 1023) / 1024), dim3(1024), 0, s, lf, p, n_leaves,
+                                         gen_sym ? 1 : 0, valid_mask, idx, reinterpret_cast<long long *>(count), err));
 }
 
 void launch_prune(int game, TreeArena ar, SearchParams p, const int32_t *actions, int32_t *noise_req,

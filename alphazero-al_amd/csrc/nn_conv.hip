@@ -114,6 +114,10 @@ struct EmbedIn {
     const uint16_t *emb_own, *emb_opp; // (32,) bf16
     const uint16_t *pos;               // (42, 32) bf16
     const int32_t  *gather;            // compact sample b shows row gather[b] (NULL: b)
+    // features == nullptr: the planes are built from the leaf POSITIONS instead (no feature tensor in HBM):
+    // two bitboards (bit = 7 * column + height, Connect4.h:15-29), side to move, symmetry id (1 = mirrored)
+    const uint64_t *bb_p1, *bb_p2;
+    const int32_t  *turn, *sym;
 };
 
 template <int CIN, bool NORM, bool RESID, bool EMBED = false>
@@ -214,13 +218,29 @@ __global__ void __launch_bounds__(256, 2) k_conv_block(const uint16_t *x, const 
         const bool live = b < B;
         int64_t row = !live ? 0 : (em.gather != nullptr ? em.gather[b] : b);
         if (row < 0 || row >= rows_total) row = 0;                    // never dereference an index outside the rows
-        const float *fs = em.features + row * (3 * CELLS);
+        if (em.features != nullptr) {
+            const float *fs = em.features + row * (3 * CELLS);
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int s = lane + 64 * i;
-            const bool ok = live && s < VPS;
-            pl_own[i] = ok ? fs[s / VPC] : 0.0f;
-            pl_opp[i] = ok ? fs[CELLS + s / VPC] : 0.0f;
+            for (int i = 0; i < PER; ++i) {
+                const int s = lane + 64 * i;
+                const bool ok = live && s < VPS;
+                pl_own[i] = ok ? fs[s / VPC] : 0.0f;
+                pl_opp[i] = ok ? fs[CELLS + s / VPC] : 0.0f;
+            }
+        } else {
+            // the planes MCTS_cpp.py:15-20 builds from the (symmetrised) grid, straight from the bitboards
+            const bool p1 = em.turn[row] > 0, mir = em.sym[row] != 0;
+            const uint64_t own = p1 ? em.bb_p1[row] : em.bb_p2[row], opp = p1 ? em.bb_p2[row] : em.bb_p1[row];
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int s = lane + 64 * i;
+                const bool ok = live && s < VPS;
+                const int cell = ok ? s / VPC : 0;
+                const int r = cell / COLS, c = cell - r * COLS;
+                const int bit = (mir ? COLS - 1 - c : c) * 7 + (5 - r);
+                pl_own[i] = (ok && ((own >> bit) & 1ull)) ? 1.0f : 0.0f;
+                pl_opp[i] = (ok && ((opp >> bit) & 1ull)) ? 1.0f : 0.0f;
+            }
         }
     };
     if (EMBED && static_cast<int64_t>(blockIdx.x) < ntiles) load_planes(blockIdx.x, lane);
@@ -535,7 +555,18 @@ int az_nn_stem_embed(const float *features, const void *emb_own, const void *emb
 {
     if (batch <= 0 || features == nullptr) return 1;
     EmbedIn em{features, static_cast<const uint16_t *>(emb_own), static_cast<const uint16_t *>(emb_opp),
-               static_cast<const uint16_t *>(pos), gather};
+               static_cast<const uint16_t *>(pos), gather, nullptr, nullptr, nullptr, nullptr};
+    return launch<32, false, false, true>(nullptr, weight_ohwi, bias, nullptr, nullptr, y, batch, 0.0f, batch_dev,
+                                          static_cast<hipStream_t>(stream), em);
+}
+
+int az_nn_stem_embed_positions(const az_nn_positions *positions, const void *emb_own, const void *emb_opp, const void *pos,
+                               const void *weight_ohwi, const void *bias, void *y, int64_t batch, const int32_t *gather,
+                               const int64_t *batch_dev, void *stream)
+{
+    if (batch <= 0 || positions == nullptr || !positions->bb_p1 || !positions->bb_p2 || !positions->turn || !positions->sym) return 1;
+    EmbedIn em{nullptr, static_cast<const uint16_t *>(emb_own), static_cast<const uint16_t *>(emb_opp),
+               static_cast<const uint16_t *>(pos), gather, positions->bb_p1, positions->bb_p2, positions->turn, positions->sym};
     return launch<32, false, false, true>(nullptr, weight_ohwi, bias, nullptr, nullptr, y, batch, 0.0f, batch_dev,
                                           static_cast<hipStream_t>(stream), em);
 }

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "az_nn.h"
+#include "board_sym.h"
 
 struct az_nn_model {
     int kind = AZ_NN_KIND_CONNECT4_CNN;
@@ -113,6 +114,49 @@ __global__ void __launch_bounds__(256) k_hash_eval(const float *features, const 
         ml[row] = OTHELLO ? (v / 32.0f - 1.0f) : (v / 2.0f);
     }
 }
+
+// the same function of the position a leaf shows under its symmetry id, from the bitboards: one thread per sample
+template <bool OTHELLO>
+__global__ void __launch_bounds__(256) k_hash_eval_positions(az_nn_positions pos, const uint8_t *mask, float *probs, float *wdl,
+                                                             float *ml, int64_t batch, const int32_t *rows, const int64_t *n_rows)
+{
+    constexpr int A = OTHELLO ? 65 : 7;
+    const int64_t b = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    int64_t n = batch;
+    if (n_rows != nullptr && *n_rows < n) n = *n_rows;
+    if (b >= n) return;
+    const int64_t row = rows != nullptr ? rows[b] : b;
+    if (row < 0 || row >= batch) return;
+    uint64_t bb0 = pos.bb_p1[row], bb1 = pos.bb_p2[row];
+    const int sym = pos.sym[row];
+    if (OTHELLO) { bb0 = az::othello_sym(bb0, sym); bb1 = az::othello_sym(bb1, sym); }
+    else if (sym) { bb0 = az::mirror_columns(bb0); bb1 = az::mirror_columns(bb1); }
+    const uint64_t h = position_hash(bb0, bb1, pos.turn[row] > 0);
+    const uint8_t *mk = mask != nullptr ? mask + row * A : nullptr;
+    if (!OTHELLO) {
+        for (int a = 0; a < 7; ++a) {
+            const float p = static_cast<float>(1 + ((h >> (4 * a)) & 15)) / 16.0f;
+            probs[row * 7 + a] = (mk == nullptr || mk[a]) ? p : 0.0f;
+        }
+    } else {
+        for (int k = 0; k < 5; ++k) {
+            uint64_t hk = h + 0x9E3779B97F4A7C15ull * static_cast<uint64_t>(k + 1);
+            hk ^= hk >> 29; hk *= 0xBF58476D1CE4E5B9ull; hk ^= hk >> 32;
+            for (int j = 0; j < 16 && k * 16 + j < 65; ++j) {
+                const int a = k * 16 + j;
+                const float p = static_cast<float>(1 + ((hk >> (4 * j)) & 15)) / 16.0f;
+                probs[row * 65 + a] = (mk == nullptr || mk[a]) ? p : 0.0f;
+            }
+        }
+    }
+    const uint64_t w0 = 1 + ((h >> 28) & 31), w1 = 1 + ((h >> 33) & 31), w2 = 1 + ((h >> 38) & 31);
+    const float tot = static_cast<float>(w0 + w1 + w2);
+    wdl[row * 3 + 0] = static_cast<float>(w0) / tot;
+    wdl[row * 3 + 1] = static_cast<float>(w1) / tot;
+    wdl[row * 3 + 2] = static_cast<float>(w2) / tot;
+    const float v = static_cast<float>((h >> 43) & 63);
+    ml[row] = OTHELLO ? (v / 32.0f - 1.0f) : (v / 2.0f);
+}
 }
 
 extern "C" {
@@ -154,13 +198,43 @@ uint64_t az_nn_model_scratch_bytes(const az_nn_model *m, int64_t batch)
     return batch > 0 ? static_cast<uint64_t>(2 * batch * kTokenBytes) : 0;
 }
 
+static int forward_impl(const az_nn_model *m, const float *features, const az_nn_positions *positions, const uint8_t *mask,
+                        float *probs, float *wdl, float *moves_left, int64_t batch, const int32_t *rows,
+                        const int64_t *n_rows, void *scratch, uint64_t scratch_bytes, void *stream);
+
 int az_nn_model_forward(const az_nn_model *m, const float *features, const uint8_t *mask, float *probs,
                         float *wdl, float *moves_left, int64_t batch, const int32_t *rows,
                         const int64_t *n_rows, void *scratch, uint64_t scratch_bytes, void *stream)
 {
-    if (m == nullptr || features == nullptr || probs == nullptr || wdl == nullptr || moves_left == nullptr) return 1;
+    if (features == nullptr) return 1;
+    return forward_impl(m, features, nullptr, mask, probs, wdl, moves_left, batch, rows, n_rows, scratch, scratch_bytes, stream);
+}
+
+int az_nn_model_forward_positions(const az_nn_model *m, const az_nn_positions *positions, const uint8_t *mask, float *probs,
+                                  float *wdl, float *moves_left, int64_t batch, const int32_t *rows,
+                                  const int64_t *n_rows, void *scratch, uint64_t scratch_bytes, void *stream)
+{
+    if (positions == nullptr || !positions->bb_p1 || !positions->bb_p2 || !positions->turn || !positions->sym) return 1;
+    return forward_impl(m, nullptr, positions, mask, probs, wdl, moves_left, batch, rows, n_rows, scratch, scratch_bytes, stream);
+}
+
+static int forward_impl(const az_nn_model *m, const float *features, const az_nn_positions *positions, const uint8_t *mask,
+                        float *probs, float *wdl, float *moves_left, int64_t batch, const int32_t *rows,
+                        const int64_t *n_rows, void *scratch, uint64_t scratch_bytes, void *stream)
+{
+    if (m == nullptr || probs == nullptr || wdl == nullptr || moves_left == nullptr) return 1;
     if (batch <= 0) return batch == 0 ? 0 : 1;
     if ((rows == nullptr) != (n_rows == nullptr)) return 1;
+    if (m->kind != AZ_NN_KIND_CONNECT4_CNN && positions != nullptr) {
+        const dim3 grid(static_cast<unsigned>((batch + 255) / 256)), block(256);
+        if (m->kind == AZ_NN_KIND_HASH_OTHELLO)
+            hipLaunchKernelGGL(k_hash_eval_positions<true>, grid, block, 0, static_cast<hipStream_t>(stream), *positions, mask, probs,
+                               wdl, moves_left, batch, rows, n_rows);
+        else
+            hipLaunchKernelGGL(k_hash_eval_positions<false>, grid, block, 0, static_cast<hipStream_t>(stream), *positions, mask, probs,
+                               wdl, moves_left, batch, rows, n_rows);
+        return 0;
+    }
     if (m->kind != AZ_NN_KIND_CONNECT4_CNN) {
         const dim3 grid(static_cast<unsigned>((batch + 3) / 4)), block(256);
         if (m->kind == AZ_NN_KIND_HASH_OTHELLO)
@@ -192,7 +266,9 @@ int az_nn_model_forward(const az_nn_model *m, const float *features, const uint8
     auto begin = [&](int kd) { if (timed && slot[kd] >= 0) (void)hipEventRecord(g_prof.start[kd][slot[kd]], hs); };
     auto end = [&](int kd) { if (timed && slot[kd] >= 0) (void)hipEventRecord(g_prof.stop[kd][slot[kd]], hs); };
     begin(AZ_NN_PROFILE_STEM);
-    int rc = az_nn_stem_embed(features, w.emb_own, w.emb_opp, w.pos, w.stem_w, w.stem_b, a, batch, rows, n_rows, stream);
+    int rc = positions != nullptr
+        ? az_nn_stem_embed_positions(positions, w.emb_own, w.emb_opp, w.pos, w.stem_w, w.stem_b, a, batch, rows, n_rows, stream)
+        : az_nn_stem_embed(features, w.emb_own, w.emb_opp, w.pos, w.stem_w, w.stem_b, a, batch, rows, n_rows, stream);
     end(AZ_NN_PROFILE_STEM);
     for (int i = 0; rc == 0 && i < w.n_blocks; ++i) {
         if (i == 0) begin(AZ_NN_PROFILE_CONV);

@@ -20,6 +20,7 @@
 
 #include <cstdint>
 
+#include "board_sym.h"
 #include "games.h"
 #include "kernels.h"
 
@@ -32,32 +33,6 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x)
     x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull;
     x ^= x >> 33;
     return x;
-}
-
-__device__ __forceinline__ uint64_t mirror_columns(uint64_t b)       // 7 bits per column (Connect4.h:249-262)
-{
-    uint64_t r = 0;
-#pragma unroll
-    for (int c = 0; c < 7; ++c) r |= ((b >> (7 * c)) & 0x7full) << (7 * (6 - c));
-    return r;
-}
-
-// Othello boards under the symmetries the search draws ({0, 2, 6, 7}, Othello.h:45,312-326): 2 = rotation
-// by 180 degrees (bit i -> 63 - i), 6 = transposition, 7 = anti-transposition (transpose, then rotate)
-__device__ __forceinline__ uint64_t transpose8x8(uint64_t x)
-{
-    uint64_t t;
-    t = 0x0f0f0f0f00000000ull & (x ^ (x << 28)); x ^= t ^ (t >> 28);
-    t = 0x3333000033330000ull & (x ^ (x << 14)); x ^= t ^ (t >> 14);
-    t = 0x5500550055005500ull & (x ^ (x << 7));  x ^= t ^ (t >> 7);
-    return x;
-}
-__device__ __forceinline__ uint64_t othello_sym(uint64_t b, int sym)
-{
-    if (sym == 2) return __brevll(b);
-    if (sym == 6) return transpose8x8(b);
-    if (sym == 7) return __brevll(transpose8x8(b));
-    return b;
 }
 
 // Geometry of a game's table: values = policy[A], relative wdl[3], auxiliary value; an entry is the key

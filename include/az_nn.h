@@ -52,6 +52,17 @@ int az_nn_conv_block(const void *x, int c_in, const void *weight_ohwi, const voi
 int az_nn_stem_embed(const float *features, const void *emb_own, const void *emb_opp, const void *pos,
                      const void *weight_ohwi, const void *bias, void *y, int64_t batch, const int32_t *gather,
                      const int64_t *batch_dev, void *stream);
+/* The same with the planes built from leaf POSITIONS in HBM instead of a feature tensor: per row two
+ * bitboards (bit = 7 * column + height, Connect4.h:15-29; player +1 / player -1), the side to move and the
+ * symmetry id the leaf is shown under (1 = columns mirrored, Connect4.h:249-262) - what selection leaves
+ * behind for every leaf.  Saves the 504-byte feature row per leaf and the kernel that writes it. */
+typedef struct az_nn_positions {
+    const uint64_t *bb_p1, *bb_p2;
+    const int32_t *turn, *sym;
+} az_nn_positions;
+int az_nn_stem_embed_positions(const az_nn_positions *positions, const void *emb_own, const void *emb_opp, const void *pos,
+                               const void *weight_ohwi, const void *bias, void *y, int64_t batch, const int32_t *gather,
+                               const int64_t *batch_dev, void *stream);
 /* The whole gated attention block as a single MFMA kernel (nn_attn.hip):
  *   y = x + o_proj(sigmoid(gate) * softmax(qnorm(Q) knorm(K)^T / 4) V),  [Q|K|V|gate] = qkvg(RMSNorm(x))
  * (Network.py:51-93).  x, y (batch, 42, 64); qkvg_w (196, 64) row-major [out][in] with rows
@@ -133,6 +144,11 @@ uint64_t az_nn_model_scratch_bytes(const az_nn_model *m, int64_t batch);
 int az_nn_model_forward(const az_nn_model *m, const float *features, const uint8_t *mask, float *probs,
                         float *wdl, float *moves_left, int64_t batch, const int32_t *rows,
                         const int64_t *n_rows, void *scratch, uint64_t scratch_bytes, void *stream);
+/* az_nn_model_forward with the leaves given as positions (az_nn_positions above; Othello: bit = 8 * row + col,
+ * symmetry ids of Othello.h:45) instead of feature planes: what az_mcts_dev_search feeds the evaluator. */
+int az_nn_model_forward_positions(const az_nn_model *m, const az_nn_positions *positions, const uint8_t *mask, float *probs,
+                                  float *wdl, float *moves_left, int64_t batch, const int32_t *rows,
+                                  const int64_t *n_rows, void *scratch, uint64_t scratch_bytes, void *stream);
 /* Kernel timing inside az_nn_model_forward (bench.py's roofline of the evaluator, measured on the
  * launches of the timed region instead of a synthetic one): enable = n >= 1 puts a HIP event pair
  * around the FIRST residual convolution block of every n-th forward call (process-wide, at most
