@@ -125,13 +125,14 @@ struct EventRing {
 // static geometry of a game as the host needs it
 struct Geo {
     int actions, cells, rows, cols, stats, max_path, sym_choices;
+    int max_edges;      // most legal moves a position can have = records an expansion can append (Othello: 33)
 };
 
 Geo geo_of(int game)
 {
     if (game == AZ_GAME_OTHELLO)
-        return Geo{az::OT_ACTIONS, az::OT_CELLS, 8, 8, az::OT_STATS, az::OT_MAX_PATH, 4};
-    return Geo{az::C4_ACTIONS, az::C4_CELLS, az::C4_ROWS, az::C4_COLS, az::C4_STATS, az::C4_MAX_PATH, 2};
+        return Geo{az::OT_ACTIONS, az::OT_CELLS, 8, 8, az::OT_STATS, az::OT_MAX_PATH, 4, 33};
+    return Geo{az::C4_ACTIONS, az::C4_CELLS, az::C4_ROWS, az::C4_COLS, az::C4_STATS, az::C4_MAX_PATH, 2, 7};
 }
 
 constexpr int64_t kInitialSlots = 4096;
@@ -379,7 +380,7 @@ struct az_mcts {
         // compact the trees that could not take two more plies' worth of growth where they are
         // (AZ_COMPACT_ALWAYS=1: every tree at every re-rooting)
         static const bool always = getenv("AZ_COMPACT_ALWAYS") != nullptr && getenv("AZ_COMPACT_ALWAYS")[0] == '1';
-        const int64_t above = always ? 0 : std::max<int64_t>(S / 8, S - 2 * std::max<int64_t>(last_extra, geo.actions));
+        const int64_t above = always ? 0 : std::max<int64_t>(S / 8, S - 2 * std::max<int64_t>(last_extra, geo.max_edges));
         az::launch_prune(game, arena(), params(), actions_dev, noise_req, dev_noise, s, noise_replay, max_live.p, err.p,
                          static_cast<int>(above));
         HIP_OK(hipMemcpyAsync(const_cast<int *>(&live_ring[q % 8]), max_live.p, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -544,7 +545,7 @@ void host_backprop(az_mcts *m, int K, bool vl, const float *policy, const float 
     if (vl) require(m->vl_stride == K, "backprop_batch_vl: K differs from the preceding search_batch_vl");
     const size_t total = static_cast<size_t>(B) * K;
     ls.ensure(total);
-    m->ensure_room(static_cast<int64_t>(K) * A);
+    m->ensure_room(static_cast<int64_t>(K) * m->geo.max_edges);
 
     // Dirichlet noise for roots expanded by this call, drawn in env order (MCTS.h:347-363)
     m->io_noise.ensure(static_cast<size_t>(B) * A, true);
@@ -778,7 +779,7 @@ void rollout_common_begin(az_mcts *m, const int8_t *boards, const int32_t *turns
     HIP_OK(hipMemset(m->plain_leaf.sym.p, 0, sizeof(int32_t) * B));
     m->io_policy.ensure(static_cast<size_t>(B) * A); m->io_d.ensure(B); m->io_p1.ensure(B);
     m->io_p2.ensure(B); m->io_ml.ensure(B); m->io_is_term.ensure(B);
-    m->ensure_room(static_cast<int64_t>(n_playout) * A);
+    m->ensure_room(static_cast<int64_t>(n_playout) * m->geo.max_edges);
     m->last_select_vl = false;
 }
 }  // namespace
@@ -911,7 +912,7 @@ void dev_prepare(az_mcts *m, int K, int64_t sims_per_tree, hipStream_t s, bool w
     require(K >= 1, "dev_prepare: K must be >= 1");
     HIP_OK(hipSetDevice(m->device));
     const size_t total = static_cast<size_t>(m->B) * K;
-    const int64_t extra = sims_per_tree * m->geo.actions;
+    const int64_t extra = sims_per_tree * m->geo.max_edges;
     // Reading the trees' fill (`used`), moving the arenas or the leaf buffers, refreshing the tables:
     // all of that must see what the kernels already enqueued have done, and must not pull memory
     // from under them.  Wait for them first - once per many calls (the host-side bound `used_bound`
@@ -1100,7 +1101,7 @@ int az_mcts_dev_search(az_mcts *m, const az_nn_model *model, int n_playout, int 
         HIP_OK(hipSetDevice(m->device));
         const size_t total = static_cast<size_t>(m->B) * K;
         const size_t scratch = az_nn_model_scratch_bytes(model, static_cast<int64_t>(total));
-        const int64_t extra = static_cast<int64_t>(n_playout) * m->geo.actions;
+        const int64_t extra = static_cast<int64_t>(n_playout) * m->geo.max_edges;
         const bool grows = total > m->vl_leaf.slot.n || total > m->ev_rows.n || scratch > m->ev_scratch.n ||
                            m->room_needs_device(extra) || (use_table && m->tt_keys.n < 2 * total);
         // anything below that allocates, frees or reads a buffer the stream's kernels use waits for them first

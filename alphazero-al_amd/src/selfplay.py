@@ -89,7 +89,7 @@ class DeviceSelfPlay:
             # growth per half: a tree is compacted once it could not take two more plies where it is, i.e.
             # every few plies; the engine checks the bound every ply from the occupancy the prune kernel
             # reports and grows the arenas if a tree ever needs more (a device-wide stop and a copy).
-            want = 6 * self.n_playout * self.search.action_size
+            want = 6 * self.n_playout * (7 if game == "Connect4" else 33)      # 33: most legal moves an Othello position has
             free_bytes, _ = torch.cuda.mem_get_info(dev)
             reserve_slots = min(want, int(free_bytes // 2) // (self.B * 2 * 48))
         if reserve_slots and int(reserve_slots) > 4096:

@@ -70,7 +70,7 @@ def select_kernel_name():
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30, help="timed plies (one ply in every game each)")
+    ap.add_argument("--steps", type=int, default=100, help="timed plies (one ply in every game each); the default keeps the timed region at ~4 s")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--lead-in", type=int, default=12,
                     help="untimed plies played before the warm-up so that the timed region sees games of all ages, "

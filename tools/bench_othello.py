@@ -30,12 +30,14 @@ def main():
     torch.manual_seed(1234)
     torch.backends.cudnn.benchmark = True
     if evaluator == "hash":
-        from src.hash_eval import HashEvaluator
-        net = HashEvaluator(dev)
+        from src.hash_eval import OthelloHashEvaluator
+        net = OthelloHashEvaluator(dev)
     else:
         net = OthelloNet(device=dev).to(memory_format=torch.channels_last)
     sp = DeviceSelfPlay(net, games, n_playout=n_playout, vl_batch=4, game="Othello", score_utility_factor=0.15,
-                        score_scale=8.0, seed=0, reserve_slots=int(os.environ.get("AZ_RESERVE_SLOTS", "16384")))
+                        score_scale=8.0, seed=0,
+                        reserve_slots=int(os.environ["AZ_RESERVE_SLOTS"]) if "AZ_RESERVE_SLOTS" in os.environ else None,
+                        table_log2=int(os.environ.get("TABLE_LOG2", "0")))
     for i in range(lead):
         t = time.perf_counter()
         sp.step()
@@ -58,7 +60,8 @@ def main():
                                     "OthelloNet h_dim 256, 3 residual blocks, random init, " +
                                     ("HIP twin (nn_othello.hip convolutions)" if type(sp.fused.fast).__name__ == "FastOthelloNet"
                                      else "torch module under bf16 autocast (library kernels)")),
-                      "timed_plies": plies, "lead_in_plies": lead}), flush=True)
+                      "timed_plies": plies, "lead_in_plies": lead,
+                      "transposition_table": (sp.fused.table_stats() if sp.fused.table_log2 else None)}), flush=True)
 
 
 if __name__ == "__main__":
