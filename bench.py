@@ -118,6 +118,8 @@ W._BACKENDS['Connect4'] = O.BatchedMCTS_Connect4
 """
     else:
         kind, games = "reference", args.cpu_games
+        if args.evaluator == "hash":            # tree-only leg: no network on the CPU either, so a sample of the default size lasts 40 ms
+            games, args.cpu_plies = max(games, 4096), max(args.cpu_plies, 8)
         log(f"cpu_baseline: reference C++/OpenMP search + CNN on {cores} host threads ...")
         head = f"""
 import sys, time, json, os
