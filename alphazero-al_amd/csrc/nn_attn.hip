@@ -63,17 +63,24 @@ __device__ __forceinline__ bf16x8 as_bf16x8(const V8 &v)
     return r.b;
 }
 __device__ __forceinline__ float bf1(const uint16_t *p) { return __uint_as_float(static_cast<uint32_t>(*p) << 16); }
+// Reductions over the 4 lane groups that share lane & 15 (the rows of a 16-lane column) on the vector ALU:
+// v_permlane16_swap / v_permlane32_swap (gfx950) hand every lane its partner across rows {0,1},{2,3} and
+// across the wavefront's halves - two instructions per step where __shfl_xor takes a trip through the LDS
+// crossbar (ds_bpermute + address + wait) each.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float col_sum(float v)   // sum over the 4 lane groups that share lane & 15
 {
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
+    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r.x) + __uint_as_float(r.y);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
 }
 __device__ __forceinline__ float col_max(float v)
 {
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    v = fmaxf(v, __shfl_xor(v, 32, 64));
-    return v;
+    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
 }
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)

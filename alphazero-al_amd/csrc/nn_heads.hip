@@ -103,9 +103,12 @@ __device__ __forceinline__ float wave_sum(float v)  // over the wavefront, retur
 }
 __device__ __forceinline__ float col_sum(float v)   // over the 4 lane groups that share lane & 15
 {
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
+    // v_permlane16_swap / v_permlane32_swap (gfx950): the partner row / half arrives through the vector ALU
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r.x) + __uint_as_float(r.y);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
 }
 // LDS traffic between lanes of ONE wavefront: the LDS executes a wavefront's instructions in
 // order, so only the compiler has to be stopped from moving accesses across this point.
