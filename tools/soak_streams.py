@@ -21,7 +21,13 @@ def main():
     games = int(sys.argv[3]) if len(sys.argv) > 3 else 8192
     torch.manual_seed(1234)
     net = Connect4Net(device=torch.device("cuda", 0)).eval()
-    sp = StreamedSelfPlay(net, games, streams=P, n_playout=200, vl_batch=4, reserve_slots=49152)
+    n_playout = int(os.environ.get("N_PLAYOUT", "200"))
+    if os.environ.get("EVALUATOR") == "hash":
+        from src.hash_eval import HashEvaluator
+        net = HashEvaluator("cuda")
+    # default reservation (six plies' growth per arena half): the run shows that no tree outgrows it
+    sp = StreamedSelfPlay(net, games, streams=P, n_playout=n_playout, vl_batch=4)
+    cap0 = [int(__import__("src.fused", fromlist=["lib"]).lib().az_mcts_capacity(p.h)) for p in sp.parts]
     t0 = time.perf_counter()
     done = 0
     while done < plies:
@@ -34,8 +40,15 @@ def main():
         print(f"streams={P} plies={done} positions={tot['positions']} games={tot['games']} "
               f"({tot['p1_wins']}/{tot['p2_wins']}/{tot['draws']}) {tot['positions'] / el:,.0f} positions/s", flush=True)
     cnt = sp.engine_counters()
-    assert tot["positions"] == plies * games and cnt["sims"] == plies * games * 200, (tot, cnt)
-    print("ok", cnt, flush=True)
+    assert tot["positions"] == plies * games and cnt["sims"] == plies * games * n_playout, (tot, cnt)
+    from src import fused as F
+    cap1 = [int(F.lib().az_mcts_capacity(p.h)) for p in sp.parts]
+    used = []
+    for p in sp.parts:
+        v = F.C.c_int64()
+        F.check(F.lib().az_mcts_max_used(p.h, F.C.byref(v)))
+        used.append(v.value)
+    print("ok", cnt, "arena records per half: reserved", cap0, "now", cap1, "fullest tree now", used, flush=True)
 
 
 if __name__ == "__main__":
