@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "az_nn.h"
 
@@ -87,7 +88,8 @@ __device__ __forceinline__ float col_max(float v)
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k((a), (b), (c), 0, 0, 0)
 
 // qkvg: (196, 64) row-major [out][in]: rows 0-63 Q, 64-127 K, 128-191 V, 192-195 gate
-__global__ void __launch_bounds__(256, 2) k_attn_block(const uint16_t *x, const uint16_t *pre_w, const uint16_t *qkvg,
+template <int MINB>      // workgroups per CU the register budget is cut for (2: 190 VGPRs, no spills; 3: 168 with 25 spilled)
+__global__ void __launch_bounds__(256, MINB) k_attn_block(const uint16_t *x, const uint16_t *pre_w, const uint16_t *qkvg,
                                                     const uint16_t *qn_w, const uint16_t *kn_w, const uint16_t *o_w,
                                                     uint16_t *y, int64_t B, float eps, const int64_t *batch_dev)
 {
@@ -324,11 +326,20 @@ int az_nn_attn_block(const void *x, const void *prenorm_w, const void *qkvg_w, c
     if (batch <= 0) return 1;
     const int64_t wgs = (batch + 3) / 4;
     const unsigned grid = static_cast<unsigned>(wgs < 1024 ? wgs : 1024);
-    hipLaunchKernelGGL(k_attn_block, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const uint16_t *>(x), static_cast<const uint16_t *>(prenorm_w),
-                       static_cast<const uint16_t *>(qkvg_w), static_cast<const uint16_t *>(q_norm_w),
-                       static_cast<const uint16_t *>(k_norm_w), static_cast<const uint16_t *>(o_w),
-                       static_cast<uint16_t *>(y), batch, eps, batch_dev);
+    static const int occ = [] { const char *e = getenv("AZ_ATTN_OCC"); const int v = e ? atoi(e) : 2; return (v == 3 || v == 4) ? v : 2; }();
+    auto go = [&](auto kern, unsigned g) {
+        hipLaunchKernelGGL(kern, dim3(g), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           static_cast<const uint16_t *>(x), static_cast<const uint16_t *>(prenorm_w),
+                           static_cast<const uint16_t *>(qkvg_w), static_cast<const uint16_t *>(q_norm_w),
+                           static_cast<const uint16_t *>(k_norm_w), static_cast<const uint16_t *>(o_w),
+                           static_cast<uint16_t *>(y), batch, eps, batch_dev);
+    };
+    (void)grid;
+    const unsigned cap = 256u * static_cast<unsigned>(occ) * 2u;       // two rounds of resident workgroups
+    const unsigned g = static_cast<unsigned>(wgs < cap ? wgs : cap);
+    if (occ == 3) go(k_attn_block<3>, g);
+    else if (occ == 4) go(k_attn_block<4>, g);
+    else go(k_attn_block<2>, g);
     return 0;
 }
 

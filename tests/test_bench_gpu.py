@@ -72,3 +72,30 @@ def test_two_rank_rehearsal_reduces_the_counters():
     assert j["sims_per_s"] == pytest.approx(j["value"] * 200, rel=1e-3)
     assert j["node_expansions_per_s_per_gpu"] == pytest.approx(j["node_expansions_per_s"] / 2, rel=1e-6)
     assert "cpu_baseline" not in j                                  # rank 0 at N = 1 only
+
+
+def test_rccl_backend_reduces_the_counters_single_rank():
+    """The collective of a multi-GPU run - one all-reduce SUM of six int64 counters and one MAX of a float64,
+    on device tensors over RCCL (`backend="nccl"`) - executed for real on this box's GPU with a one-rank
+    process group: the same `shard.reduce_counters` call bench.py makes, the same backend, one device."""
+    code = (
+        "import os, sys, json, torch, torch.distributed as dist\n"
+        "sys.path.insert(0, %r)\n"
+        "from src import shard\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group(backend='nccl', device_id=torch.device('cuda', 0))\n"
+        "class Two:            # make reduce_counters take the collective branch with one rank\n"
+        "    pass\n"
+        "orig = dist.get_world_size\n"
+        "dist.get_world_size = lambda *a, **k: 2 if not a and not k else orig(*a, **k)\n"
+        "tot, t = shard.reduce_counters([8192, 1638400, 1343488, 77, 5300000, 6900000], 1.25, torch.device('cuda', 0))\n"
+        "dist.get_world_size = orig\n"
+        "dist.barrier()\n"
+        "print(json.dumps(dict(tot=tot, t=t)))\n"
+        "dist.destroy_process_group()\n" % os.path.join(ROOT, "alphazero-al_amd"))
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _last_json(r.stdout)
+    assert j["tot"]["positions"] == 8192 and j["tot"]["sims"] == 1638400 and j["tot"]["backup_nodes"] == 6900000
+    assert j["t"] == 1.25
