@@ -1093,7 +1093,8 @@ int az_mcts_dev_search(az_mcts *m, const az_nn_model *model, int n_playout, int 
         require(model != nullptr, "dev_search: no evaluator model");
         const int kind = az_nn_model_kind(model);
         require(kind == (m->game == AZ_GAME_CONNECT4 ? AZ_NN_KIND_HASH_CONNECT4 : AZ_NN_KIND_HASH_OTHELLO) ||
-                    (kind == AZ_NN_KIND_CONNECT4_CNN && m->game == AZ_GAME_CONNECT4),
+                    (kind == AZ_NN_KIND_CONNECT4_CNN && m->game == AZ_GAME_CONNECT4) ||
+                    (kind == AZ_NN_KIND_OTHELLO_CNN && m->game == AZ_GAME_OTHELLO),
                 "dev_search: the evaluator model does not belong to this engine's game");
         require(K >= 1 && n_playout >= 0, "dev_search: K must be >= 1 and n_playout >= 0");
         require(!use_table || m->tt_entries.p != nullptr, "dev_search: no table (az_mcts_dev_tt_create)");

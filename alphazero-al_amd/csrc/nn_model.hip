@@ -18,10 +18,13 @@
 struct az_nn_model {
     int kind = AZ_NN_KIND_CONNECT4_CNN;
     az_nn_model_weights w{};
+    az_nn_othello_weights ow{};
 };
 
 namespace {
 constexpr int64_t kTokenBytes = 42 * 64 * 2;     // one sample's (42, 64) bf16 activations
+// Othello: bytes per sample of the embedded tokens, a 10x10 and an 8x8 map of 256 channels, the 8-channel bottleneck
+constexpr uint64_t kOtTok = 64 * 32 * 2, kOtMap10 = 100 * 256 * 2, kOtMap8 = 64 * 256 * 2, kOtNeck = 64 * 8 * 2;
 
 // az_nn_model_profile: event pairs around the launches of every stride-th forward call - the stem, the
 // FIRST residual block, the attention block and the heads, one ring per kind (process-wide; the
@@ -188,12 +191,29 @@ int az_nn_model_create_hash(int game, az_nn_model **out)
     return 0;
 }
 
+int az_nn_model_create_othello(const az_nn_othello_weights *w, az_nn_model **out)
+{
+    if (w == nullptr || out == nullptr || w->embed_table == nullptr) return 1;
+    if (w->n_body < 2 || w->n_body % 2 != 0 || w->n_convs != w->n_body + 2 || w->n_convs > AZ_NN_OTHELLO_MAX_CONVS) return 1;
+    for (int i = 0; i < w->n_convs; ++i)
+        if (!w->conv[i].w_packed || !w->conv[i].post_scale || !w->conv[i].post_shift) return 1;
+    if (!w->dual_w16 || !w->dual_scale16 || !w->dual_shift16 || !w->heads.board_w || !w->heads.a_fc_wt) return 1;
+    auto *m = new (std::nothrow) az_nn_model();
+    if (m == nullptr) return 1;
+    m->kind = AZ_NN_KIND_OTHELLO_CNN;
+    m->ow = *w;
+    *out = m;
+    return 0;
+}
+
 void az_nn_model_destroy(az_nn_model *m) { delete m; }
 
 int az_nn_model_kind(const az_nn_model *m) { return m ? m->kind : -1; }
 
 uint64_t az_nn_model_scratch_bytes(const az_nn_model *m, int64_t batch)
 {
+    if (m != nullptr && m->kind == AZ_NN_KIND_OTHELLO_CNN)       // tokens, three 10x10x256 maps, two 8x8x256 maps, the bottleneck
+        return batch > 0 ? static_cast<uint64_t>(batch) * (kOtTok + 3 * kOtMap10 + 2 * kOtMap8 + kOtNeck) : 0;
     if (m != nullptr && m->kind != AZ_NN_KIND_CONNECT4_CNN) return 0;
     return batch > 0 ? static_cast<uint64_t>(2 * batch * kTokenBytes) : 0;
 }
@@ -225,6 +245,40 @@ static int forward_impl(const az_nn_model *m, const float *features, const az_nn
     if (m == nullptr || probs == nullptr || wdl == nullptr || moves_left == nullptr) return 1;
     if (batch <= 0) return batch == 0 ? 0 : 1;
     if ((rows == nullptr) != (n_rows == nullptr)) return 1;
+    if (m->kind == AZ_NN_KIND_OTHELLO_CNN) {
+        // Othello/Network.py:213-227 on the kernels of nn_othello.hip / nn_othello_heads.hip; needs positions + masks
+        if (positions == nullptr || mask == nullptr) return 1;
+        if (scratch == nullptr || scratch_bytes < az_nn_model_scratch_bytes(m, batch)) return 1;
+        const az_nn_othello_weights &o = m->ow;
+        char *base = static_cast<char *>(scratch);
+        char *tok = base; base += batch * kOtTok;
+        char *map[3];
+        for (auto &p : map) { p = base; base += batch * kOtMap10; }
+        char *pa = base; base += batch * kOtMap8;
+        char *pb = base; base += batch * kOtMap8;
+        char *neck = base;
+        auto conv = [&](int i, const void *x, const void *res, void *y) {
+            const az_nn_othello_conv_layer &l = o.conv[i];
+            return az_nn_othello_conv(x, l.w_packed, l.pre_scale, l.pre_shift, l.post_scale, l.post_shift, l.residual ? res : nullptr,
+                                      y, batch, l.c_in, l.h_in, l.pad, 1, n_rows, stream);
+        };
+        int rc = az_nn_othello_embed(positions, mask, o.embed_table, tok, batch, rows, n_rows, stream);
+        int cur = 0;                                      // map[cur] holds the running hidden state
+        if (rc == 0) rc = conv(0, tok, nullptr, map[cur]);
+        for (int i = 1; rc == 0 && i + 1 < o.n_body; i += 2) {
+            const int y1 = (cur + 1) % 3, y2 = (cur + 2) % 3;
+            rc = conv(i, map[cur], nullptr, map[y1]);
+            if (rc == 0) rc = conv(i + 1, map[y1], map[cur], map[y2]);
+            cur = y2;
+        }
+        const int hid = (cur + 1) % 3;
+        if (rc == 0) rc = conv(o.n_body - 1, map[cur], nullptr, map[hid]);
+        if (rc == 0) rc = conv(o.n_body, map[hid], nullptr, pa);
+        if (rc == 0) rc = conv(o.n_body + 1, pa, nullptr, pb);
+        if (rc == 0) rc = az_nn_othello_conv_narrow(map[hid], o.dual_w16, o.dual_scale16, o.dual_shift16, neck, batch, n_rows, stream);
+        if (rc == 0) rc = az_nn_othello_heads(pb, neck, &o.heads, probs, wdl, moves_left, batch, rows, n_rows, stream);
+        return rc;
+    }
     if (m->kind != AZ_NN_KIND_CONNECT4_CNN && positions != nullptr) {
         const dim3 grid(static_cast<unsigned>((batch + 255) / 256)), block(256);
         if (m->kind == AZ_NN_KIND_HASH_OTHELLO)

@@ -55,8 +55,10 @@ __device__ __forceinline__ float silu(float v) { return __fdividef(v, 1.0f + __e
 template <int CIN, int HI, int PAD, bool PRE, bool RES, bool SILU>
 __global__ void __launch_bounds__(256, 2) k_oth_conv(const uint16_t *x, const uint16_t *wp, const float *pre_s,
                                                      const float *pre_b, const float *post_s, const float *post_b,
-                                                     const uint16_t *res, uint16_t *y, int64_t B, int dbg)
+                                                     const uint16_t *res, uint16_t *y, int64_t B, int dbg,
+                                                     const int64_t *batch_dev)
 {
+    if (batch_dev != nullptr && *batch_dev < B) B = *batch_dev;      // compact batch whose size only the device knows
     constexpr int PW = HI + 2 * PAD;          // padded width
     constexpr int HO = PW - 2;                // output width
     constexpr int NT = HO * HO;               // output tokens
@@ -274,7 +276,7 @@ __global__ void __launch_bounds__(256, 2) k_oth_conv(const uint16_t *x, const ui
 
 template <int CIN, int HI, int PAD, bool PRE, bool RES, bool SILU>
 int launch(const void *x, const void *wp, const float *pre_s, const float *pre_b, const float *post_s,
-           const float *post_b, const void *res, void *y, int64_t B, hipStream_t s)
+           const float *post_b, const void *res, void *y, int64_t B, const int64_t *batch_dev, hipStream_t s)
 {
     constexpr int PW = HI + 2 * PAD, HO = PW - 2;
     constexpr int IMG = PW * PW * CIN * 2, STAGE = HO * HO * ROWB;
@@ -290,7 +292,7 @@ int launch(const void *x, const void *wp, const float *pre_s, const float *pre_b
     const unsigned grid = static_cast<unsigned>(B < 512 ? B : 512);      // two workgroups per CU, persistent over samples
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), SMEM, s, static_cast<const uint16_t *>(x),
                        static_cast<const uint16_t *>(wp), pre_s, pre_b, post_s, post_b,
-                       static_cast<const uint16_t *>(res), static_cast<uint16_t *>(y), B, dbg);
+                       static_cast<const uint16_t *>(res), static_cast<uint16_t *>(y), B, dbg, batch_dev);
     return 0;
 }
 
@@ -300,8 +302,10 @@ int launch(const void *x, const void *wp, const float *pre_s, const float *pre_b
 // in fragment order) are the same lines for every wavefront and stay in L1.  The kernel is bound by
 // the copy of the sample into LDS, not by its 72 MFMAs per wavefront.
 __global__ void __launch_bounds__(256, 2) k_oth_conv_narrow(const uint16_t *x, const uint16_t *wp, const float *post_s,
-                                                            const float *post_b, uint16_t *y, int64_t B)
+                                                            const float *post_b, uint16_t *y, int64_t B,
+                                                            const int64_t *batch_dev)
 {
+    if (batch_dev != nullptr && *batch_dev < B) B = *batch_dev;
     constexpr int CIN = 256, HI = 10, PW = 10, HO = 8, NT = 64, CELLB = CIN * 2, CPC = 32, KPT = 8;
     extern __shared__ __align__(16) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -362,7 +366,8 @@ __global__ void __launch_bounds__(256, 2) k_oth_conv_narrow(const uint16_t *x, c
 
 extern "C" int az_nn_othello_conv(const void *x, const void *w_packed, const float *pre_scale, const float *pre_shift,
                                   const float *post_scale, const float *post_shift, const void *residual, void *y,
-                                  int64_t batch, int c_in, int h_in, int pad, int apply_silu, void *stream)
+                                  int64_t batch, int c_in, int h_in, int pad, int apply_silu, const int64_t *batch_dev,
+                                  void *stream)
 {
     if (batch <= 0 || x == nullptr || w_packed == nullptr || y == nullptr || post_scale == nullptr || post_shift == nullptr)
         return 1;
@@ -370,7 +375,7 @@ extern "C" int az_nn_othello_conv(const void *x, const void *w_packed, const flo
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool pre = pre_scale != nullptr, res = residual != nullptr;
 #define AZ_OTH(CIN, HI, PAD, PRE, RES, SILU) \
-    return launch<CIN, HI, PAD, PRE, RES, SILU>(x, w_packed, pre_scale, pre_shift, post_scale, post_shift, residual, y, batch, s)
+    return launch<CIN, HI, PAD, PRE, RES, SILU>(x, w_packed, pre_scale, pre_shift, post_scale, post_shift, residual, y, batch, batch_dev, s)
     if (c_in == 32 && h_in == 8 && pad == 2 && !pre && !res && apply_silu) AZ_OTH(32, 8, 2, false, false, true);
     if (c_in == 256 && h_in == 10 && pad == 1 && pre && !res && apply_silu) AZ_OTH(256, 10, 1, true, false, true);
     if (c_in == 256 && h_in == 10 && pad == 1 && pre && res && apply_silu) AZ_OTH(256, 10, 1, true, true, true);
@@ -382,7 +387,8 @@ extern "C" int az_nn_othello_conv(const void *x, const void *w_packed, const flo
 }
 
 extern "C" int az_nn_othello_conv_narrow(const void *x, const void *w_packed16, const float *post_scale16,
-                                         const float *post_shift16, void *y, int64_t batch, void *stream)
+                                         const float *post_shift16, void *y, int64_t batch, const int64_t *batch_dev,
+                                         void *stream)
 {
     if (batch <= 0 || x == nullptr || w_packed16 == nullptr || y == nullptr || post_scale16 == nullptr || post_shift16 == nullptr)
         return 1;
@@ -396,6 +402,6 @@ extern "C" int az_nn_othello_conv_narrow(const void *x, const void *w_packed16, 
     const unsigned grid = static_cast<unsigned>(batch < 768 ? batch : 768);       // three workgroups per CU
     hipLaunchKernelGGL(k_oth_conv_narrow, dim3(grid), dim3(256), SMEM, static_cast<hipStream_t>(stream),
                        static_cast<const uint16_t *>(x), static_cast<const uint16_t *>(w_packed16), post_scale16, post_shift16,
-                       static_cast<uint16_t *>(y), batch);
+                       static_cast<uint16_t *>(y), batch, batch_dev);
     return 0;
 }

@@ -18,6 +18,22 @@ import torch.nn.functional as F
 from src.fast_net import glue
 
 
+class _HeadsW(C.Structure):          # az_nn_othello_heads_weights (include/az_nn.h)
+    _PTRS = ("board_w", "pass_norm_w", "pass_fc_w", "v_conv_w", "v_bn_s", "v_bn_b", "v_fc_w", "v_fc_b", "a_fc_wt", "a_fc_b",
+             "a_norm_w", "a_out_w")
+    _fields_ = [(n, C.c_void_p) for n in _PTRS] + [(n, C.c_float) for n in ("board_b", "pass_fc_b", "a_out_b", "aux_to_score", "eps")]
+
+
+class _ConvLayer(C.Structure):       # az_nn_othello_conv_layer
+    _fields_ = [(n, C.c_void_p) for n in ("w_packed", "pre_scale", "pre_shift", "post_scale", "post_shift")] + \
+               [(n, C.c_int32) for n in ("residual", "c_in", "h_in", "pad")]
+
+
+class _OthelloW(C.Structure):        # az_nn_othello_weights
+    _fields_ = [("embed_table", C.c_void_p), ("n_body", C.c_int32), ("n_convs", C.c_int32), ("conv", _ConvLayer * 16),
+                ("dual_w16", C.c_void_p), ("dual_scale16", C.c_void_p), ("dual_shift16", C.c_void_p), ("heads", _HeadsW)]
+
+
 def _bn_affine(bn):
     scale = (bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps))
     shift = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
@@ -57,7 +73,7 @@ class FastOthelloNet(torch.nn.Module):
         self.score_scale = float(getattr(net, "score_scale", 8.0))
         L = glue()
         vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
-        L.az_nn_othello_conv.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
+        L.az_nn_othello_conv.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp]
         self._L = L
         dev = self.device
         ones = torch.ones(256, device=dev)
@@ -101,9 +117,63 @@ class FastOthelloNet(torch.nn.Module):
         self.dual_s = torch.ones(16, device=dev)
         self.dual_b = torch.zeros(16, device=dev)
         self.dual_s[:8], self.dual_b[:8] = s8.to(dev), b8.to(dev)
-        L.az_nn_othello_conv_narrow.argtypes = [vp, vp, vp, vp, vp, i64, vp]
+        L.az_nn_othello_conv_narrow.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp]
         self.v_conv_w = dh.value_out[0].weight.detach().float().reshape(8, 72).t().contiguous()    # (72, 8)
         self.v_bn = tuple(t.to(dev).view(1, 8, 1) for t in _bn_affine(dh.value_out[1]))
+
+    def native_model(self):
+        """az_nn_model* (kind OTHELLO_CNN, include/az_nn.h) over this twin's buffers: embedding, the
+        convolutions, the bottleneck and both heads as one C call - what az_mcts_dev_search runs inside its
+        loop for Othello; it reads the leaves' bitboards and evaluates only the rows a device-side list names."""
+        if self.__dict__.get("_model") is not None:
+            return self.__dict__["_model"]
+        dev, f32 = self.device, torch.float32
+        net = self.net
+        keep = {}
+
+        def t(x):
+            y = x.detach().to(dev, f32).contiguous()
+            keep[len(keep)] = y
+            return y.data_ptr()
+        w = _OthelloW()
+        w.embed_table = self.embed_table.data_ptr()
+        w.n_body, w.n_convs = self.n_body, self.n_body + 2
+        assert w.n_convs <= 16 and w.n_convs == len(self.layers)
+        for i, (wp, pre, post, res, c_in, h_in, pad) in enumerate(self.layers):
+            L = w.conv[i]
+            L.w_packed = wp.data_ptr()
+            L.pre_scale, L.pre_shift = (pre[0].data_ptr(), pre[1].data_ptr()) if pre is not None else (None, None)
+            L.post_scale, L.post_shift = post[0].data_ptr(), post[1].data_ptr()
+            L.residual, L.c_in, L.h_in, L.pad = int(bool(res)), c_in, h_in, pad
+        w.dual_w16, w.dual_scale16, w.dual_shift16 = self.dual_w.data_ptr(), self.dual_s.data_ptr(), self.dual_b.data_ptr()
+        ph, dh, h = net.policy_head, net.dual_head, w.heads
+        h.board_w = self.board_w.data_ptr()
+        h.pass_norm_w, h.pass_fc_w = t(ph.pass_norm.weight), t(ph.pass_fc.weight.reshape(-1))
+        h.v_conv_w = self.v_conv_w.data_ptr()
+        h.v_bn_s, h.v_bn_b = t(self.v_bn[0].reshape(-1)), t(self.v_bn[1].reshape(-1))
+        h.v_fc_w, h.v_fc_b = t(dh.value_out[5].weight), t(dh.value_out[5].bias)
+        h.a_fc_wt, h.a_fc_b = t(dh.aux_out[1].weight.t()), t(dh.aux_out[1].bias)
+        h.a_norm_w, h.a_out_w = t(dh.aux_out[2].weight), t(dh.aux_out[5].weight.reshape(-1))
+        h.board_b, h.pass_fc_b, h.a_out_b = self.board_b, float(ph.pass_fc.bias.item()), float(dh.aux_out[5].bias.item())
+        h.aux_to_score = float(self.aux_target_offset) / self.score_scale
+        h.eps = 1e-5
+        L = self._L
+        L.az_nn_model_create_othello.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        handle = C.c_void_p()
+        if L.az_nn_model_create_othello(C.byref(w), C.byref(handle)) != 0:
+            raise RuntimeError("az_nn_model_create_othello refused the weights")
+        self.__dict__["_model_keep"] = keep
+        self.__dict__["_model"] = handle
+        return handle
+
+    def __del__(self):
+        try:
+            h = self.__dict__.get("_model")
+            if h is not None:
+                self.__dict__["_model"] = None
+                self._L.az_nn_model_destroy(h)
+        except Exception:
+            pass
 
     def _conv(self, x, layer, residual, stream):
         wp, pre, post, res, c_in, h_in, pad = layer
@@ -112,7 +182,7 @@ class FastOthelloNet(torch.nn.Module):
         y = torch.empty((bsz, ho, ho, 256), dtype=torch.bfloat16, device=self.device)
         rc = self._L.az_nn_othello_conv(x.data_ptr(), wp.data_ptr(), None if pre is None else pre[0].data_ptr(),
                                         None if pre is None else pre[1].data_ptr(), post[0].data_ptr(), post[1].data_ptr(),
-                                        residual.data_ptr() if res else None, y.data_ptr(), bsz, c_in, h_in, pad, 1, stream)
+                                        residual.data_ptr() if res else None, y.data_ptr(), bsz, c_in, h_in, pad, 1, None, stream)
         if rc != 0:
             raise RuntimeError("az_nn_othello_conv refused its arguments (%d)" % rc)
         return y
@@ -151,7 +221,7 @@ class FastOthelloNet(torch.nn.Module):
         dh = net.dual_head
         h8 = torch.empty((hidden.shape[0], 8, 8, 8), dtype=torch.bfloat16, device=self.device)
         if self._L.az_nn_othello_conv_narrow(hidden.data_ptr(), self.dual_w.data_ptr(), self.dual_s.data_ptr(),
-                                             self.dual_b.data_ptr(), h8.data_ptr(), hidden.shape[0], s) != 0:
+                                             self.dual_b.data_ptr(), h8.data_ptr(), hidden.shape[0], None, s) != 0:
             raise RuntimeError("az_nn_othello_conv_narrow refused its arguments")
         h8 = h8.permute(0, 3, 1, 2).float().contiguous()                                            # (B, 8 channels, 8, 8)
         # 3x3 stride-2 convolution 8 -> 8 on the 8x8 map as strided window views + one small GEMM (the

@@ -192,7 +192,7 @@ class FusedSearch:
                     raise RuntimeError("az_nn_model_create_hash failed")
                 self._hash_model = h
             return self._hash_model
-        if self.fast is None or self.game_name != "Connect4":
+        if self.fast is None or not hasattr(self.fast, "native_model"):
             return None
         return self.fast.native_model()
 

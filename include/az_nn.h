@@ -174,17 +174,63 @@ int az_nn_model_profile_read_kernels(double out_ms[4], int64_t out_launches[4]);
  * w_packed: the (256, c_in, 3, 3) weight as bf16 in fragment order [tap][c_in / 32][channel tile 16]
  * [lane 64 = 16 * k group + channel][8 input channels] (fast_othello.pack_conv_weight).
  * Supported (c_in, h_in, pad): (32, 8, 2), (256, 10, 1) with or without pre / residual, (256, 10, 0),
- * (256, 8, 1); apply_silu must be 1.  Returns 0, 1 on an unsupported combination. */
+ * (256, 8, 1); apply_silu must be 1.  batch_dev (or NULL): device count of a compact batch, as above.
+ * Returns 0, 1 on an unsupported combination. */
 int az_nn_othello_conv(const void *x, const void *w_packed, const float *pre_scale, const float *pre_shift,
                        const float *post_scale, const float *post_shift, const void *residual, void *y,
-                       int64_t batch, int c_in, int h_in, int pad, int apply_silu, void *stream);
+                       int64_t batch, int c_in, int h_in, int pad, int apply_silu, const int64_t *batch_dev, void *stream);
 
 /* The dual head's 8-channel bottleneck of the same network (Othello/Network.py:81-83): 3x3, no padding,
  * 256 -> 8 channels on the 10x10 map, BatchNorm, SiLU.  x (batch, 10, 10, 256) NHWC bf16 -> y (batch, 8, 8, 8)
  * NHWC bf16.  w_packed16: the (8, 256, 3, 3) weight padded with zeros to 16 output channels, packed like
  * az_nn_othello_conv's with ONE channel tile; post_*16: 16 floats each (entries 8..15 unused). */
 int az_nn_othello_conv_narrow(const void *x, const void *w_packed16, const float *post_scale16,
-                              const float *post_shift16, void *y, int64_t batch, void *stream);
+                              const float *post_shift16, void *y, int64_t batch, const int64_t *batch_dev, void *stream);
+
+/* The thin ends of the same network as kernels (nn_othello_heads.hip), so that the whole Othello evaluator can
+ * be one native object.  az_nn_othello_embed: leaf positions (bit = 8 * row + col, symmetry ids of
+ * Othello.h:45) + action masks (rows x 65, the symmetrised frame) -> tokens (batch, 8, 8, 32) NHWC bf16 through a
+ * (64 cells x 4 kinds, 32) bf16 table: kind 0 own stone, 1 opponent stone, 2 empty and legal, 3 empty and illegal
+ * (Othello/Network.py:201-211).  az_nn_othello_heads: the policy stem's output (batch, 8, 8, 256) and the
+ * bottleneck (batch, 8, 8, 8), both NHWC bf16 -> probs (rows, 65), relative wdl (rows, 3), score utility (rows):
+ * what `predict` returns (Othello/Network.py:40-104, 229-261).  gather / scatter / batch_dev: compact batches. */
+typedef struct az_nn_othello_heads_weights {
+    const void  *board_w;                 /* policy_head.board_out.weight, 256 bf16 */
+    const float *pass_norm_w, *pass_fc_w; /* policy_head.pass_norm.weight, pass_fc.weight: 256 floats each */
+    const float *v_conv_w;                /* dual_head.value_out[0].weight as (72, 8): [ci*9 + ky*3 + kx][co] */
+    const float *v_bn_s, *v_bn_b;         /* its BatchNorm as scale / shift, 8 each */
+    const float *v_fc_w, *v_fc_b;         /* value_out[5]: (3, 72) row-major, (3) */
+    const float *a_fc_wt, *a_fc_b;        /* aux_out[1].weight TRANSPOSED to (512 in, 512 out), bias (512) */
+    const float *a_norm_w, *a_out_w;      /* aux_out[2].weight (512), aux_out[5].weight (512) */
+    float board_b, pass_fc_b, a_out_b;
+    float aux_to_score;                   /* aux_target_offset / score_scale (64 / 8) */
+    float eps;                            /* the RMSNorms' epsilon (1e-5) */
+} az_nn_othello_heads_weights;
+int az_nn_othello_embed(const az_nn_positions *positions, const uint8_t *mask, const void *embed_table, void *tokens,
+                        int64_t batch, const int32_t *gather, const int64_t *batch_dev, void *stream);
+int az_nn_othello_heads(const void *policy_map, const void *bottleneck, const az_nn_othello_heads_weights *w, float *probs,
+                        float *wdl, float *utility, int64_t batch, const int32_t *scatter, const int64_t *batch_dev, void *stream);
+
+/* The whole Othello evaluator as one az_nn_model (kind AZ_NN_KIND_OTHELLO_CNN) for az_mcts_dev_search /
+ * az_nn_model_forward_positions: embedding, the body's convolutions in order - conv[0] the stem (32 -> 256,
+ * 8x8, pad 2), then pairs (conv1, conv2 with the block's input as residual), then the last body convolution;
+ * conv[n_body], conv[n_body + 1] the policy stem (10x10 pad 0, 8x8 pad 1) - the bottleneck convolution, the heads. */
+#define AZ_NN_OTHELLO_MAX_CONVS 16
+typedef struct az_nn_othello_conv_layer {
+    const void *w_packed;
+    const float *pre_scale, *pre_shift, *post_scale, *post_shift;
+    int32_t residual, c_in, h_in, pad;
+} az_nn_othello_conv_layer;
+typedef struct az_nn_othello_weights {
+    const void *embed_table;
+    int32_t n_body, n_convs;                                   /* n_convs = n_body + 2 */
+    az_nn_othello_conv_layer conv[AZ_NN_OTHELLO_MAX_CONVS];
+    const void *dual_w16;                                      /* as az_nn_othello_conv_narrow */
+    const float *dual_scale16, *dual_shift16;
+    az_nn_othello_heads_weights heads;
+} az_nn_othello_weights;
+#define AZ_NN_KIND_OTHELLO_CNN 3
+int az_nn_model_create_othello(const az_nn_othello_weights *w, az_nn_model **out);
 
 #ifdef __cplusplus
 }

@@ -129,10 +129,10 @@ def test_evaluator_model_object_host_side(built):
     assert L.az_nn_model_create(C.byref(bad), C.byref(h)) == 1
     assert L.az_nn_model_create(None, C.byref(h)) == 1
     # the Othello convolution entry point refuses what it does not implement, without a device
-    L.az_nn_othello_conv.argtypes = [C.c_void_p] * 8 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
-    assert L.az_nn_othello_conv(fake, fake, None, None, fake, fake, None, fake, 4, 64, 8, 1, 1, None) == 1
-    assert L.az_nn_othello_conv(fake, fake, None, None, fake, fake, None, fake, 0, 256, 10, 1, 1, None) == 1
-    assert L.az_nn_othello_conv(fake, fake, fake, None, fake, fake, None, fake, 4, 256, 10, 1, 1, None) == 1
+    L.az_nn_othello_conv.argtypes = [C.c_void_p] * 8 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    assert L.az_nn_othello_conv(fake, fake, None, None, fake, fake, None, fake, 4, 64, 8, 1, 1, None, None) == 1
+    assert L.az_nn_othello_conv(fake, fake, None, None, fake, fake, None, fake, 0, 256, 10, 1, 1, None, None) == 1
+    assert L.az_nn_othello_conv(fake, fake, fake, None, fake, fake, None, fake, 4, 256, 10, 1, 1, None, None) == 1
 
 
 def test_host_generator_matches_libstdcxx(built):

@@ -912,7 +912,7 @@ def test_othello_conv_kernel_matches_torch(env):
     from src.fast_net import glue
     L = glue()
     vp = C.c_void_p
-    L.az_nn_othello_conv.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    L.az_nn_othello_conv.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     F = torch.nn.functional
     bf = lambda t: t.to(torch.bfloat16).float()                                   # noqa: E731
     g = torch.Generator(device="cuda"); g.manual_seed(5)
@@ -929,7 +929,7 @@ def test_othello_conv_kernel_matches_torch(env):
         wp = pack_conv_weight(w)
         rc = L.az_nn_othello_conv(x.data_ptr(), wp.data_ptr(), pre_s.data_ptr() if pre else None, pre_b.data_ptr() if pre else None,
                                   post_s.data_ptr(), post_b.data_ptr(), r.data_ptr() if res else None, y.data_ptr(), bsz, cin, hi, pad, 1,
-                                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                                  None, C.c_void_p(torch.cuda.current_stream().cuda_stream))
         assert rc == 0
         xin = x.float()
         if pre:
@@ -945,7 +945,7 @@ def test_othello_conv_kernel_matches_torch(env):
     assert L.az_nn_othello_conv(x.data_ptr(), wp.data_ptr(), None, None, post_s.data_ptr(), post_b.data_ptr(), None, y.data_ptr(),
                                 4, 64, 8, 1, 1, None) == 1                       # unsupported geometry is refused
     # the narrow kernel of the dual head's bottleneck: 256 -> 8 channels, no padding
-    L.az_nn_othello_conv_narrow.argtypes = [vp, vp, vp, vp, vp, C.c_int64, vp]
+    L.az_nn_othello_conv_narrow.argtypes = [vp, vp, vp, vp, vp, C.c_int64, vp, vp]
     for bsz in (3, 1000):
         x = rn(bsz, 10, 10, 256).to(torch.bfloat16)
         w = rn(8, 256, 3, 3) * (1.5 / 2304 ** 0.5)
@@ -954,7 +954,7 @@ def test_othello_conv_kernel_matches_torch(env):
         s16[:8], b16[:8] = rn(8) * 0.2 + 1.0, rn(8) * 0.2
         y = torch.full((bsz, 8, 8, 8), 7.0, dtype=torch.bfloat16, device="cuda")
         assert L.az_nn_othello_conv_narrow(x.data_ptr(), pack_conv_weight(w16).data_ptr(), s16.data_ptr(), b16.data_ptr(), y.data_ptr(),
-                                           bsz, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+                                           bsz, None, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
         conv = F.conv2d(x.float().permute(0, 3, 1, 2), bf(w)).permute(0, 2, 3, 1)
         want = bf(F.silu(bf(conv * s16[:8] + b16[:8])))
         torch.cuda.synchronize()
@@ -1016,6 +1016,96 @@ def test_fast_othello_twin_matches_module(env):
         assert (w.get_visits_count().sum(1) == 39).all()
     st = w._fused.table_stats()
     assert w._fused.table_log2 == 18 and st["hits"] > 0.4 * st["lookups"], st      # the second search replays the first
+
+
+def test_othello_native_model_object(env):
+    """The Othello evaluator as ONE native object (az_nn_model, kind OTHELLO_CNN: embedding from the leaves'
+    bitboards, the convolutions, the bottleneck and both heads in HIP) against the twin it is built from -
+    whose thin ends are torch operations - and against the module: within bf16 error; a leaf given under a
+    symmetry id equals, bit for bit, the transformed position given under id 0; compact lists evaluate and
+    scatter only the named rows; and the native loop engages for Othello with the network."""
+    torch = env["torch"]
+    import ctypes as C
+    from src.fast_othello import FastOthelloNet
+    F = env["F"]
+    net = _rand_othello_net(env, 5)
+    twin = FastOthelloNet(net)
+    model = twin.native_model()
+    L = F.lib()
+    vp, i64 = C.c_void_p, C.c_int64
+
+    class Pos(C.Structure):
+        _fields_ = [("bb_p1", vp), ("bb_p2", vp), ("turn", vp), ("sym", vp)]
+    L.az_nn_model_forward_positions.argtypes = [vp, C.POINTER(Pos), vp, vp, vp, vp, i64, vp, vp, vp, C.c_uint64, vp]
+    L.az_nn_model_scratch_bytes.argtypes = [vp, i64]; L.az_nn_model_scratch_bytes.restype = C.c_uint64
+    rng = np.random.default_rng(12)
+    n = 150
+    boards, turns = S.ot_openings(rng, n, 44, 0)
+
+    def masks_of(bs, ts):
+        m = np.zeros((len(bs), 65), np.uint8)
+        for i in range(len(bs)):
+            mv = S.ot_moves(bs[i], int(ts[i]))
+            m[i, mv if mv else [64]] = 1
+        return m
+
+    def run(bs, ts, syms, masks, rows=None):
+        bb0, bb1 = S.ot_bitboards(bs)
+        dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).astype(dt)).cuda()          # noqa: E731
+        t0, t1 = dev(bb0.view(np.int64), np.int64), dev(bb1.view(np.int64), np.int64)
+        tt, sy, mk = dev(ts, np.int32), dev(syms, np.int32), dev(masks, np.uint8)
+        k = len(bs)
+        probs = torch.zeros((k, 65), device="cuda"); wdl = torch.zeros((k, 3), device="cuda"); ut = torch.zeros(k, device="cuda")
+        nb = int(L.az_nn_model_scratch_bytes(model, k))
+        scratch = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        pos = Pos(t0.data_ptr(), t1.data_ptr(), tt.data_ptr(), sy.data_ptr())
+        r_ptr = n_ptr = None
+        if rows is not None:
+            r = dev(rows, np.int32); c = torch.tensor([len(rows)], dtype=torch.int64, device="cuda")
+            r_ptr, n_ptr = r.data_ptr(), c.data_ptr()
+        assert L.az_nn_model_forward_positions(model, C.byref(pos), mk.data_ptr(), probs.data_ptr(), wdl.data_ptr(), ut.data_ptr(),
+                                               k, r_ptr, n_ptr, scratch.data_ptr(), nb, F._stream()) == 0
+        torch.cuda.synchronize()
+        return probs, wdl, ut
+
+    masks = masks_of(boards, turns)
+    p, w, u = run(boards, turns, np.zeros(n, np.int32), masks)
+    planes = np.stack([(boards == turns[:, None, None]), (boards == -turns[:, None, None]),
+                       np.ones_like(boards) * turns[:, None, None]], 1).astype(np.float32)
+    x = torch.from_numpy(planes).cuda(); m = torch.from_numpy(masks.astype(bool)).cuda()
+    p1, w1, u1 = twin.predict_device(x, m)
+    with torch.no_grad():
+        lp, lv, aux = net(x, m)
+    p0, w0, u0 = lp.exp(), lv.exp(), torch.atan(aux * 8.0) * (2.0 / np.pi)
+    err = dict(vs_twin=((p - p1).abs().max().item(), (w - w1).abs().max().item(), (u - u1).abs().max().item()),
+               vs_module=((p - p0).abs().max().item(), (w - w0).abs().max().item(), (u - u0).abs().max().item()))
+    print("othello native model:", err)
+    assert err["vs_twin"][0] < 5e-3 and err["vs_twin"][1] < 1e-2 and err["vs_twin"][2] < 3e-2, err
+    assert err["vs_module"][0] < 0.03 and err["vs_module"][1] < 0.06 and err["vs_module"][2] < 0.15, err
+    assert abs(p.sum(1) - 1).max().item() < 1e-5 and abs(w.sum(1) - 1).max().item() < 1e-5
+    # symmetry ids: the leaf under id s == the transformed position under id 0 (apply_symmetry moves stone i to T_s(i))
+    tf = {2: lambda b: b[::-1, ::-1], 6: lambda b: b.T, 7: lambda b: b[::-1, ::-1].T}
+    for sid, f in tf.items():
+        tb = np.stack([np.ascontiguousarray(f(b)) for b in boards])
+        tm = masks_of(tb, turns)
+        pa, wa, ua = run(boards, turns, np.full(n, sid, np.int32), tm)
+        pb, wb, ub = run(tb, turns, np.zeros(n, np.int32), tm)
+        assert torch.equal(pa, pb) and torch.equal(wa, wb) and torch.equal(ua, ub), sid
+    # compact list
+    rows = np.array([7, 3, 140, 21], np.int32)
+    pc, wc, uc = run(boards, turns, np.zeros(n, np.int32), masks, rows=rows)
+    idx = torch.from_numpy(rows.astype(np.int64)).cuda()
+    assert torch.equal(pc[idx], p[idx]) and torch.equal(wc[idx], w[idx]) and torch.equal(uc[idx], u[idx])
+    rest = torch.ones(n, dtype=torch.bool, device="cuda"); rest[idx] = False
+    assert pc[rest].abs().max().item() == 0.0
+    # the device loop: above 512 trees the whole search is one native call for Othello as well
+    b600 = np.tile(boards, (4, 1, 1)); t600 = np.tile(turns, 4)
+    wr = env["W"].BatchedMCTS(600, 1.4, 800, 0.3, 24, noise_epsilon=0.25, fpu_reduction=0.2, use_symmetry=True,
+                              game_name="Othello", score_utility_factor=0.15, score_scale=8.0)
+    wr.batch_playout(net, b600, t600, vl_batch=4, fused=True)
+    assert wr._fused._native_model() is not None and isinstance(wr._fused.fast, FastOthelloNet)
+    st = np.array(wr.mcts.get_all_root_stats())
+    assert (st[:, 0] == 24).all() and (wr.get_visits_count().sum(1) == 23).all()
 
 
 def test_native_search_refuses_misuse_and_reservation_is_sized(env):

@@ -12,7 +12,7 @@ from src.fast_net import glue  # noqa: E402
 from src.fast_othello import pack_conv_weight  # noqa: E402
 
 L = glue()
-L.az_nn_othello_conv.argtypes = [C.c_void_p] * 8 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+L.az_nn_othello_conv.argtypes = [C.c_void_p] * 8 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 x = torch.randn(B, 10, 10, 256, device="cuda").to(torch.bfloat16)
 w = pack_conv_weight(torch.randn(256, 256, 3, 3, device="cuda") * 0.03)
@@ -23,7 +23,7 @@ s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 def run(pre, res):
     return L.az_nn_othello_conv(x.data_ptr(), w.data_ptr(), ones.data_ptr() if pre else None, zeros.data_ptr() if pre else None,
-                                ones.data_ptr(), zeros.data_ptr(), x.data_ptr() if res else None, y.data_ptr(), B, 256, 10, 1, 1, s)
+                                ones.data_ptr(), zeros.data_ptr(), x.data_ptr() if res else None, y.data_ptr(), B, 256, 10, 1, 1, None, s)
 
 
 for pre, res in ((False, False), (True, False), (True, True)):
