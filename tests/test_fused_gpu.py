@@ -943,7 +943,7 @@ def test_othello_conv_kernel_matches_torch(env):
         err = (y.float() - want).abs()
         assert err.max().item() < 0.06 and err.mean().item() < 2e-3, (cin, hi, pad, pre, res, err.max().item(), err.mean().item())
     assert L.az_nn_othello_conv(x.data_ptr(), wp.data_ptr(), None, None, post_s.data_ptr(), post_b.data_ptr(), None, y.data_ptr(),
-                                4, 64, 8, 1, 1, None) == 1                       # unsupported geometry is refused
+                                4, 64, 8, 1, 1, None, None) == 1                 # unsupported geometry is refused
     # the narrow kernel of the dual head's bottleneck: 256 -> 8 channels, no padding
     L.az_nn_othello_conv_narrow.argtypes = [vp, vp, vp, vp, vp, C.c_int64, vp, vp]
     for bsz in (3, 1000):
