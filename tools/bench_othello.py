@@ -58,7 +58,9 @@ def main():
                       "mean_select_depth": round((c1["levels"] - c0["levels"]) / max(sims, 1), 3),
                       "evaluator": ("integer-hash evaluator" if evaluator == "hash" else
                                     "OthelloNet h_dim 256, 3 residual blocks, random init, " +
-                                    ("HIP twin (nn_othello.hip convolutions)" if type(sp.fused.fast).__name__ == "FastOthelloNet"
+                                    (("HIP twin as one native model object (nn_othello.hip, nn_othello_heads.hip; native loop)"
+                                      if sp.fused._native_model() is not None else "HIP twin (nn_othello.hip convolutions, Python loop)")
+                                     if type(sp.fused.fast).__name__ == "FastOthelloNet"
                                      else "torch module under bf16 autocast (library kernels)")),
                       "timed_plies": plies, "lead_in_plies": lead,
                       "transposition_table": (sp.fused.table_stats() if sp.fused.table_log2 else None)}), flush=True)
