@@ -178,7 +178,8 @@ int az_mcts_dev_leaves(az_mcts *m, int K, uint64_t *bb_p1, uint64_t *bb_p2, int3
 /* Root visit counts int32[n_envs*A] / root stats float32[n_envs*(6+8A)] into HBM. */
 int az_mcts_dev_counts(az_mcts *m, int32_t *counts, void *stream);
 int az_mcts_dev_root_stats(az_mcts *m, float *stats, void *stream);
-/* prune_roots with actions in HBM and Dirichlet noise from the device generator. */
+/* prune_roots with actions in HBM and Dirichlet noise from the device generator (or from az_mcts_dev_replay);
+ * trees that run out of room are compacted into their other arena half on the way (see az_mcts_reserve). */
 int az_mcts_dev_prune_roots(az_mcts *m, const int32_t *actions, void *stream);
 /* Reset the trees whose mask byte is non-zero (mask uint8[n_envs] in HBM). */
 int az_mcts_dev_reset_masked(az_mcts *m, const uint8_t *mask, void *stream);
@@ -261,7 +262,12 @@ int az_mcts_dev_tt_stats(az_mcts *m, int64_t out[4]);
 
 /* ---- capacity / instrumentation ------------------------------------------------------- */
 
-/* Make every tree arena hold at least `slots` node records (grows, never shrinks). */
+/* Tree arenas.  Every tree owns two halves of `capacity` node records and lives in one of them; a re-rooting
+ * (prune_roots) copies the subtree it keeps into the other half when the tree could not take two more
+ * searches' worth of growth where it is (the reference never reclaims a node before the next reset,
+ * MCTS.h:90-108; node numbering is not observable).  az_mcts_reserve makes every half hold at least
+ * `slots_per_tree` records (grows, never shrinks; synchronises); the engine grows by itself when a tree needs
+ * more.  az_mcts_capacity: records per half. */
 int az_mcts_reserve(az_mcts *m, int64_t slots_per_tree);
 int64_t az_mcts_capacity(const az_mcts *m);
 /* Changes whenever any device buffer the dev_* kernels address was reallocated (arena growth,
