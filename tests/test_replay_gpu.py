@@ -342,3 +342,34 @@ def test_config5_network_table_verify_and_refresh(env):
         assert inserts0 > 0
     finally:
         os.environ.pop("AZ_FUSED_GRAPH", None)
+
+
+# ---------------------------------------------------------------------------- BASELINE configs 2 and 3/4 at their own sizes
+
+def test_config2_full_size_equals_oracle(env):
+    """BASELINE config 2's per-GPU share - Connect4, 8192 games, n_playout 800 (c_base 4000), K 4, actor
+    configuration - one ply through the native loop, every tree bit-exact against the oracle (replayed
+    draws, hash evaluator): 6.5 M simulations, trees of ~4000 records, descents up to ~25 levels deep."""
+    rng = np.random.default_rng(800)
+    b, t = S.random_openings(rng, 512, 20)
+    boards = np.tile(b, (16, 1, 1)); turns = np.tile(t, 16)
+    n, K = 800, 4
+    cfg = dict(S.ACTOR_CFG, c_base=5.0 * n)
+    tape = oracle_with_tape(S.C4Game, O.BatchedMCTS_Connect4, cfg, boards, turns, n, K, 1, seed=3)
+    counts, stats = device_loop_with_tape(env, "Connect4", cfg, boards, turns, n, K, 1, tape, True)
+    _compare(tape, counts, stats)
+    assert (stats[:, :, 0] == n).all()
+
+
+def test_config3_full_size_equals_oracle(env):
+    """BASELINE config 3/4 - Othello, 4096 games, n_playout 400 (c_base 2000), K 4, score utility 0.15, noise and
+    the four symmetries on - one ply through the native loop, every tree bit-exact against the oracle."""
+    rng = np.random.default_rng(400)
+    b, t = S.ot_openings(rng, 256, 30, 0)
+    boards = np.tile(b, (16, 1, 1)); turns = np.tile(t, 16)
+    n, K = 400, 4
+    cfg = dict(S.OT_ACTOR_CFG, c_base=5.0 * n)
+    tape = oracle_with_tape(S.OthelloGame, O.BatchedMCTS_Othello, cfg, boards, turns, n, K, 1, seed=3)
+    counts, stats = device_loop_with_tape(env, "Othello", cfg, boards, turns, n, K, 1, tape, True)
+    _compare(tape, counts, stats)
+    assert (stats[:, :, 0] == n).all()
