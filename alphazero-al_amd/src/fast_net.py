@@ -114,8 +114,6 @@ class FastConnect4Net(torch.nn.Module):
         self.register_buffer("pre_w", c(sd[a + "prenorm.weight"]))
         qkvg = torch.cat([sd[a + "qkv_proj.weight"], sd[a + "gate_proj.weight"]], 0)
         self.register_buffer("qkvg_w", c(qkvg))
-        # the same projection padded to 200 outputs: 400-byte rows keep 16-byte vector alignment
-        self.register_buffer("qkvg_w_pad", c(torch.cat([qkvg, torch.zeros(4, qkvg.shape[1], device=qkvg.device)], 0)))
         self.register_buffer("o_w", c(sd[a + "o_proj.weight"]))
         self.register_buffer("qn_w", c(sd[a + "q_norm.weight"]))
         self.register_buffer("kn_w", c(sd[a + "k_norm.weight"]))
@@ -140,14 +138,12 @@ class FastConnect4Net(torch.nn.Module):
         self.register_buffer("d_aux_w", c(sd[d + "aux_out.weight"].reshape(-1)))
         self.register_buffer("d_aux_b", f(sd[d + "aux_out.bias"]))
         self.p_gate_b_host = float(sd[p + "row_gate.bias"].reshape(-1)[0].item())
-        # fused HIP glue (nn_kernels.hip) on the GPU with bf16 activations; plain torch otherwise
+        # the all-HIP forward pass (include/az_nn.h: stem with the embedding, residual blocks, attention, heads) on
+        # the GPU with bf16 activations and the reference's shapes; plain torch operations otherwise (CPU, fp32
+        # builds for the parity tests, other widths).  One switch: tests flip `hip` to compare the two.
         self.hip = (self.device.type == "cuda" and dtype == torch.bfloat16 and self.embed_dim == 32
-                    and self.h_dim == 64 and heads == 4 and os.environ.get("AZ_NN_GLUE", "1") != "0"
-                    and glue() is not None)
-        self.mfma_conv = self.hip and os.environ.get("AZ_NN_MFMA_CONV", "1") != "0"
-        self.mfma_attn = self.hip and os.environ.get("AZ_NN_MFMA_ATTN", "1") != "0"
-        self.fused_stem = self.mfma_conv and os.environ.get("AZ_NN_FUSED_STEM", "1") != "0"
-        self.fused_heads = self.mfma_conv and self.mfma_attn and os.environ.get("AZ_NN_FUSED_HEADS", "1") != "0"
+                    and self.h_dim == 64 and heads == 4 and glue() is not None)
+        self.mfma_conv = self.mfma_attn = self.fused_stem = self.fused_heads = self.hip
         self._heads_w = None
         if self.fused_heads:
             hw = HeadsWeights()
@@ -219,16 +215,10 @@ class FastConnect4Net(torch.nn.Module):
         return F.rms_norm(x, (x.shape[-1],), w, 1e-5)
 
     # ------------------------------------------------------------------ GPU path
-    def _conv_img(self, tokens, w):
-        """bias-free convolution; the bias is applied by the fused SiLU/residual kernel"""
-        bsz, _, cin = tokens.shape
-        img = tokens.view(bsz, ROWS, COLS, cin).permute(0, 3, 1, 2)
-        return F.conv2d(img, w, None, padding=1).permute(0, 2, 3, 1)         # (B, 6, 7, Cout) view
-
     @property
     def supports_compact(self):
         """predict_device(..., rows=, n_rows=, out=): evaluate only the listed rows"""
-        return bool(self.hip and self.fused_heads)
+        return bool(self.hip)
 
     @torch.no_grad()
     def predict_device(self, x, action_mask=None, rows=None, n_rows=None, out=None):
@@ -267,10 +257,8 @@ class FastConnect4Net(torch.nn.Module):
 
     @torch.no_grad()
     def _forward_hip(self, x, action_mask):
-        if self.mfma_attn and self.mfma_conv:
-            t, bsz, L, s = self._body_hip(x)
-            return self._heads_hip(t, action_mask, bsz, L, s)
-        return self._forward_hip_glue(x, action_mask)
+        t, bsz, L, s = self._body_hip(x)
+        return self._heads_hip(t, action_mask, bsz, L, s)
 
     @torch.no_grad()
     def _body_hip(self, x, rows=None, n_rows=None):
@@ -285,16 +273,9 @@ class FastConnect4Net(torch.nn.Module):
         c_dim = self.h_dim
         x = x.contiguous().float()
         t = torch.empty((bsz, CELLS, c_dim), dtype=bf, device=dev)
-        if self.fused_stem:
-            # embedding + stem convolution in one kernel: the tokens are built in LDS
-            L.az_nn_stem_embed(x.data_ptr(), self.emb_own.data_ptr(), self.emb_opp.data_ptr(), self.pos.data_ptr(),
-                               self.stem_w.data_ptr(), self.stem_b.data_ptr(), t.data_ptr(), bsz, gp, np_, s)
-        else:
-            t0 = torch.empty((bsz, CELLS, self.embed_dim), dtype=bf, device=dev)
-            L.az_nn_embed(x.data_ptr(), self.emb_own.data_ptr(), self.emb_opp.data_ptr(), self.pos.data_ptr(),
-                          t0.data_ptr(), bsz, self.embed_dim, gp, np_, s)
-            L.az_nn_conv_block(t0.data_ptr(), self.embed_dim, self.stem_w.data_ptr(), self.stem_b.data_ptr(), None,
-                               None, 0, t.data_ptr(), bsz, 1e-5, np_, s)
+        # embedding + stem convolution in one kernel: the tokens are built in LDS
+        L.az_nn_stem_embed(x.data_ptr(), self.emb_own.data_ptr(), self.emb_opp.data_ptr(), self.pos.data_ptr(),
+                           self.stem_w.data_ptr(), self.stem_b.data_ptr(), t.data_ptr(), bsz, gp, np_, s)
         for w, b, g, beta in self.res:
             t2 = torch.empty_like(t)
             L.az_nn_conv_block(t.data_ptr(), c_dim, getattr(self, w).data_ptr(), getattr(self, b).data_ptr(),
@@ -307,66 +288,10 @@ class FastConnect4Net(torch.nn.Module):
         return t2, bsz, L, s
 
     @torch.no_grad()
-    def _forward_hip_glue(self, x, action_mask):
-        L = glue()
-        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        bsz = x.shape[0]
-        dev, bf = self.device, torch.bfloat16
-        c_dim = self.h_dim
-        x = x.contiguous().float()
-        t = torch.empty((bsz, CELLS, self.embed_dim), dtype=bf, device=dev)
-        L.az_nn_embed(x.data_ptr(), self.emb_own.data_ptr(), self.emb_opp.data_ptr(), self.pos.data_ptr(),
-                      t.data_ptr(), bsz, self.embed_dim, None, None, s)
-        n_el = bsz * CELLS * c_dim
-        if self.mfma_conv:
-            # each block is one MFMA kernel (nn_conv.hip)
-            t0 = t
-            t = torch.empty((bsz, CELLS, c_dim), dtype=bf, device=dev)
-            L.az_nn_conv_block(t0.data_ptr(), self.embed_dim, self.stem_w.data_ptr(), self.stem_b.data_ptr(), None,
-                               None, 0, t.data_ptr(), bsz, 1e-5, None, s)
-            for w, b, g, beta in self.res:
-                t2 = torch.empty_like(t)
-                L.az_nn_conv_block(t.data_ptr(), c_dim, getattr(self, w).data_ptr(), getattr(self, b).data_ptr(),
-                                   getattr(self, g).data_ptr(), getattr(self, beta).data_ptr(), 1, t2.data_ptr(),
-                                   bsz, 1e-5, None, s)
-                t = t2
-            y = torch.empty_like(t)
-        else:
-            conv = self._conv_img(t, self.stem_w).contiguous()
-            t = torch.empty((bsz, CELLS, c_dim), dtype=bf, device=dev)
-            L.az_nn_silu_add(conv.data_ptr(), self.stem_b.data_ptr(), c_dim, None, t.data_ptr(), n_el, s)
-            y = torch.empty_like(t)
-            for w, b, g, beta in self.res:
-                L.az_nn_groupnorm1(t.data_ptr(), getattr(self, g).data_ptr(), getattr(self, beta).data_ptr(),
-                                   y.data_ptr(), bsz, c_dim, 1e-5, s)
-                conv = self._conv_img(y, getattr(self, w)).contiguous()
-                t2 = torch.empty_like(t)
-                L.az_nn_silu_add(conv.data_ptr(), getattr(self, b).data_ptr(), c_dim, t.data_ptr(), t2.data_ptr(), n_el, s)
-                t = t2
-        # gated attention
-        rows = bsz * CELLS
-        if self.mfma_attn:
-            t2 = torch.empty_like(t)
-            L.az_nn_attn_block(t.data_ptr(), self.pre_w.data_ptr(), self.qkvg_w.data_ptr(), self.qn_w.data_ptr(),
-                               self.kn_w.data_ptr(), self.o_w.data_ptr(), t2.data_ptr(), bsz, 1e-5, None, s)
-            return self._heads_hip(t2, action_mask, bsz, L, s)
-        L.az_nn_rmsnorm64(t.data_ptr(), self.pre_w.data_ptr(), y.data_ptr(), rows, 1e-5, s)
-        qkvg = F.linear(y.view(rows, c_dim), self.qkvg_w_pad)                 # (T, 200)
-        q = torch.empty((bsz, self.heads, CELLS, c_dim // self.heads), dtype=bf, device=dev)
-        k = torch.empty_like(q)
-        v = torch.empty_like(q)
-        gate = torch.empty((rows, self.heads), dtype=bf, device=dev)
-        L.az_nn_qkv_prep(qkvg.data_ptr(), 200, self.qn_w.data_ptr(), self.kn_w.data_ptr(), q.data_ptr(),
-                         k.data_ptr(), v.data_ptr(), gate.data_ptr(), bsz, 1e-5, s)
-        a = F.scaled_dot_product_attention(q, k, v).contiguous()
-        L.az_nn_attn_post(a.data_ptr(), gate.data_ptr(), y.data_ptr(), bsz, s)
-        t = torch.addmm(t.view(rows, c_dim), y.view(rows, c_dim), self.o_w.t()).view(bsz, CELLS, c_dim)
-        return self._heads_hip(t, action_mask, bsz, L, s)
-
-    @torch.no_grad()
     def _heads_hip(self, t, action_mask, bsz, L, s):
+        """the heads as az_nn_heads_prep + torch operations: `forward`'s log-probabilities, and what the fused
+        heads kernel (az_nn_heads, used by predict_device) is compared with in the tests"""
         dev, bf, c_dim = self.device, torch.bfloat16, self.h_dim
-        # heads
         col = torch.empty((bsz, COLS, c_dim), dtype=bf, device=dev)
         mean = torch.empty((bsz, c_dim), dtype=bf, device=dev)
         L.az_nn_heads_prep(t.data_ptr(), self.p_norm.data_ptr(), self.p_gate_w.data_ptr(), self.p_gate_b_host,
