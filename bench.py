@@ -58,7 +58,7 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("AZ_CPU_CORES", "64"))))
 
 
-PROFILE_EVERY = 4
+PROFILE_EVERY = 16       # an event pair costs the stream ~5 us: six kinds of kernel are timed, so every 16th iteration carries them (0.3 % of a step)
 
 
 def select_kernel_name():
@@ -267,13 +267,13 @@ def main():
     torch.cuda.synchronize()
     for h in handles:
         F.check(L.az_mcts_counters_reset(h))
-        F.check(L.az_mcts_profile(h, PROFILE_EVERY))      # every 4th selection / backup launch carries an event pair
+        F.check(L.az_mcts_profile(h, PROFILE_EVERY))      # every 16th selection / backup launch carries an event pair
     import ctypes as C
     from src.fast_net import glue
     G = glue()
     G.az_nn_model_profile.argtypes = [C.c_int]
     G.az_nn_model_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64)]
-    G.az_nn_model_profile(PROFILE_EVERY)                   # and every 4th first residual block of the evaluator
+    G.az_nn_model_profile(PROFILE_EVERY)                   # and every 16th forward call of the evaluator, kernel by kernel
     t_before = sp.read_totals()
 
     if world > 1:
