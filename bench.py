@@ -206,7 +206,7 @@ def conv_roofline(torch, fast, leaves, launches=20):
             "achieved": round(achieved, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4),
             "avg_launch_us": round(us, 1), "flops_per_launch": int(flops),
             "traffic": 2 * leaves * 42 * 64 * 2, "note": "dense bf16 MFMA peak; the kernel's HBM traffic equals its "
-            "algorithmic bytes (profiles/r01_pmc_fetch_write_by_kernel_final.csv)"}
+            "algorithmic bytes (profiles/r02_pmc_fetch_write_by_kernel.csv)"}
 
 
 def main():
@@ -413,7 +413,7 @@ def main():
                     "flops_per_launch": int(flops), "traffic": int(2 * live * 42 * 64 * 2),
                     "note": "HIP events around every %d-th first residual block inside the timed region (az_nn_model_profile), "
                             "event-pair overhead removed; dense bf16 MFMA peak; the kernel's HBM traffic equals its algorithmic "
-                            "bytes (profiles/r01_pmc_fetch_write_by_kernel_final.csv)" % PROFILE_EVERY,
+                            "bytes (profiles/r02_pmc_fetch_write_by_kernel.csv)" % PROFILE_EVERY,
                     "synthetic_launch": {"achieved": synth["achieved"], "avg_launch_us": synth["avg_launch_us"],
                                          "leaves": args.games * args.vl_batch // max(args.streams, 1),
                                          "note": "same kernel on random activations after the run: slower, the clock follows the data"}}
