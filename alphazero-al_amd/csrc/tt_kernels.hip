@@ -1,9 +1,10 @@
-// tt_kernels.hip - device transposition table of evaluator outputs (Connect4).
+// tt_kernels.hip - device transposition table of evaluator outputs, templated over the game.
 //
 // What the reference keeps in a Python OrderedDict (src/Cache.py:5-58, used per leaf by
 // src/MCTS_cpp.py:146-189 and 298-339): key = the leaf position AS THE EVALUATOR SEES IT (the
-// symmetrised board) + side to move, value = (policy[7], relative wdl[3], moves left).  Here:
-// a flat open-addressing table in HBM, 64-byte entries, 4-entry buckets (one 256-byte line).
+// symmetrised board) + side to move, value = (policy[A], relative wdl[3], auxiliary value).  Here:
+// a flat open-addressing table in HBM, entries of whole 64-byte lines (Connect4: one, Othello: five),
+// 4-entry buckets.
 //
 //   lookup   one thread per leaf: hit -> the cached 11 floats go straight into the arrays the
 //            backup kernel reads; miss -> the leaf's index is appended to a compact list whose

@@ -11,9 +11,11 @@ enqueued back to back on the current stream, and - once shapes are warm - replay
 hipGraph (torch.cuda.CUDAGraph), so the host issues one graph launch per iteration.
 
 Randomness (symmetry ids, Dirichlet noise) comes from the engine's counter-based device
-generator on this path; the bit-exact reference stream (host mt19937) needs the host path.
+generator on this path; the reference's own stream (host mt19937) is what the host path draws.
 With use_symmetry=False and dirichlet_alpha<=0 nothing random is consumed and this path is
-bit-identical to the host path (tests/test_fused_gpu.py).
+bit-identical to the host path (tests/test_fused_gpu.py); with randomness on, `FusedSearch.replay`
+plays recorded draws back so that the loop can be compared with the oracle bit for bit
+(tests/test_replay_gpu.py).
 """
 import ctypes as C
 import gc

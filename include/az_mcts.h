@@ -232,11 +232,11 @@ struct az_nn_model;
 int az_mcts_dev_search(az_mcts *m, const struct az_nn_model *model, int n_playout, int K, int use_table,
                        void *stream);
 
-/* ---- device transposition table of evaluator outputs (Connect4) -------------------------
+/* ---- device transposition table of evaluator outputs (both games) ------------------------
  * Replaces, for the device loop, the LRU table of the reference's wrapper (src/Cache.py:5-58 used
  * by src/MCTS_cpp.py:146-189 and 298-339): key = the symmetrised leaf position + side to move,
- * value = policy[7], relative wdl[3], moves left.  2^log2_entries entries of 64 bytes, buckets
- * of four, approximate-LRU replacement inside a bucket.  Between az_mcts_dev_select and
+ * value = policy[A], relative wdl[3], auxiliary value.  2^log2_entries entries of 64 bytes (Connect4)
+ * or 320 bytes (Othello), buckets of four, approximate-LRU replacement inside a bucket.  Between az_mcts_dev_select and
  * az_mcts_dev_backprop of one iteration:
  *   az_mcts_dev_tt_lookup   hits: the cached values are written to probs / wdl_rel / moves_left
  *                           at the leaf's flat index; misses: their flat indices are appended to
@@ -245,8 +245,9 @@ int az_mcts_dev_search(az_mcts *m, const struct az_nn_model *model, int n_playou
  *   (evaluate the rows listed in miss_idx, writing the same three arrays - az_nn.h `batch_dev`)
  *   az_mcts_dev_tt_insert   stores the freshly evaluated rows.
  * A lookup never returns a value that was not inserted for exactly its key (torn entries fail a
- * checksum and read as misses).  az_mcts_dev_tt_clear empties the table: call it whenever the
- * evaluator's weights change (MCTS_cpp.py:361-377 `refresh_cache` re-evaluates instead).
+ * checksum and read as misses).  When the evaluator's weights change the cached outputs are stale:
+ * az_mcts_dev_tt_refresh re-evaluates them in place as the reference's `refresh_cache` does
+ * (MCTS_cpp.py:361-377; Connect4), az_mcts_dev_tt_clear empties the table.
  * Statistics (synchronises): lookups, hits, inserts, entries replaced. */
 int az_mcts_dev_tt_create(az_mcts *m, int log2_entries);
 int az_mcts_dev_tt_clear(az_mcts *m, void *stream);
