@@ -348,209 +348,6 @@ __global__ void __launch_bounds__(WAVE) k_select(TreeArena ar, RootState rs, Lea
     wave_add_counter(counters, CNT_SIMS, (live && sub == 0) ? static_cast<unsigned>(K) : 0u);
 }
 
-// The K virtual-loss descents of a tree, staggered by ONE LEVEL instead of run one after the
-// other.  Descent k+1 depends on descent k only through what k leaves on the nodes it arrives at
-// (in-flight visits, the EXISTS / TERMINAL bits), and k writes those when it ARRIVES at a node -
-// one level ahead of where a descent that runs a level behind will read them.  So in step s
-// descent j works on its level s - j: all block loads of the step are issued together (up to K
-// independent HBM round trips in flight per tree instead of one), then the descents are
-// processed in ascending j with k_select's arithmetic, unchanged.  A level's stores precede the
-// next step's loads of the same records in the program order of the lane that owns them (lane =
-// sibling index), which is the ordering k_select relies on as well.  depth + K - 1 steps
-// instead of K x depth.  Results are bit-identical to k_select (tests).
-template <class G, int KMAX>
-__global__ void __launch_bounds__(WAVE) k_select_staggered(TreeArena ar, RootState rs, LeafBuf lf, SearchParams p, int K,
-                                                           int tpw, unsigned long long *counters, uint64_t *bump, long long *zero)
-{
-    constexpr int L = G::LANES;
-    const int lane = threadIdx.x;
-    if (bump != nullptr && blockIdx.x == 0 && lane == 0) *bump += 1;
-    if (zero != nullptr && blockIdx.x == 0 && lane == 0) *zero = 0;   // the live-leaf count of this iteration
-    const int sub = lane % L;
-    const int grp = lane / L;
-    const int tree = blockIdx.x * tpw + grp;
-    const bool live = grp < tpw && tree < ar.B;
-    const int t = live ? tree : 0;
-    const float tree_ne = p.noise_eps_tree != nullptr ? p.noise_eps_tree[t] : p.noise_eps;
-
-    HotRec *hot = ar.hot + tree_base(ar, t);
-    const ColdRec *cold = ar.cold + tree_base(ar, t);
-    const int root = ar.root[t];
-    HotRec rootrec = hot[root];
-    int root_infl = rootrec.n_inflight;
-    GameState rstate;
-    rstate.bb0 = rs.bb0[t]; rstate.bb1 = rs.bb1[t]; rstate.turn = rs.turn[t]; rstate.aux = rs.aux[t];
-    const size_t flat0 = static_cast<size_t>(t) * K;
-
-    // per descent: where it stands (uniform across the group)
-    int cur[KMAX], cur_lane[KMAX], depth[KMAX];
-    bool fin[KMAX];
-    HotRec R[KMAX], c[KMAX];
-    float noise[KMAX];
-    GameState st[KMAX];
-#pragma unroll
-    for (int j = 0; j < KMAX; ++j) {
-        cur[j] = root; cur_lane[j] = 0; depth[j] = 0;
-        fin[j] = !live || j >= K;
-        st[j] = rstate;
-        noise[j] = 0.0f;
-        c[j] = empty_rec();
-    }
-    unsigned n_levels = 0, n_terminal = 0;
-
-    for (int step = 0;; ++step) {
-        // ---- all loads of the step first
-        bool stop[KMAX], act[KMAX];
-#pragma unroll
-        for (int j = 0; j < KMAX; ++j) {
-            act[j] = !fin[j] && step >= j;
-            stop[j] = true;
-            if (act[j]) {
-                if (step == j) {                                     // the descent starts now: the root as it is NOW
-                    R[j] = rootrec; R[j].n_inflight = root_infl;
-                    if (sub == 0) lf.path[(flat0 + j) * G::MAX_PATH] = root;
-                }
-                const uint32_t meta = R[j].meta;
-                const int E = static_cast<int>((meta & META_NEDGE_MASK) >> META_NEDGE_SHIFT);
-                stop[j] = !(meta & META_EXPANDED) || (meta & META_TERMINAL) || E == 0;   // MCTS.h:250-258
-                c[j] = empty_rec();
-                noise[j] = 0.0f;
-                if (!stop[j] && sub < E) {
-                    c[j] = hot[R[j].child_off + sub];
-                    if (cur[j] == root && tree_ne > 0.0f) noise[j] = cold[R[j].child_off + sub].noise;
-                }
-            }
-        }
-        // ---- then the descents in order (the arithmetic of k_select)
-#pragma unroll
-        for (int j = 0; j < KMAX; ++j) {
-            if (!act[j]) continue;
-            const size_t flat = flat0 + j;
-            int32_t *path = lf.path + flat * G::MAX_PATH;
-            const uint32_t meta = R[j].meta;
-            const int E = static_cast<int>((meta & META_NEDGE_MASK) >> META_NEDGE_SHIFT);
-            int best = -1;
-            HotRec cc = c[j];
-            bool stp = stop[j];
-            if (!stp) {
-                const bool has = sub < E;
-                const bool is_root = cur[j] == root;
-                const float ne = tree_ne;
-                const bool exists = has && (cc.meta & META_EXISTS);
-                const bool real = exists && cc.n_visits > 0;
-                const float pq = mean_q(R[j].n_visits, R[j].w_p1, R[j].w_p2, (meta & META_TURN_P1) != 0);
-                const float seen_term = real ? cc.prior : 0.0f;
-                float seen = 0.0f;
-                if (L <= 8) {
-#pragma unroll
-                    for (int i = 0; i < L - 1; ++i) seen += __shfl(seen_term, i, L);
-                } else {
-                    for (int i = 0; i < E; ++i) seen += __shfl(seen_term, i, L);
-                }
-                const float scale = (1.0f + pq) / 2.0f;
-                const float eff = p.fpu_reduction * scale;
-                float fpu = fmaf(-eff, sqrtf(seen), pq);
-                fpu = (-1.0f < fpu) ? fpu : -1.0f;
-                const int pn_i = R[j].n_visits + R[j].n_inflight;
-                const float parent_n = static_cast<float>(pn_i);
-                const float parent_m = mean_m(R[j].n_visits, R[j].m_sum);
-                const float c_puct = (pn_i >= 0 && pn_i < p.tab_n)
-                    ? p.cpuct_tab[pn_i]
-                    : p.c_init + logf((parent_n + p.c_base + 1.0f) / p.c_base);
-                float eff_prior = cc.prior;
-                if (is_root && ne > 0.0f) eff_prior = fmaf(cc.prior, 1.0f - ne, ne * noise[j]);
-                float q, child_q = 0.0f, child_m = 0.0f;
-                int child_total = 0;
-                if (real) {
-                    child_total = cc.n_visits + cc.n_inflight;
-                    child_q = mean_q(cc.n_visits, cc.w_p1, cc.w_p2, (cc.meta & META_TURN_P1) != 0);
-                    child_m = mean_m(cc.n_visits, cc.m_sum);
-                    q = -child_q;
-                } else if (exists && cc.n_inflight > 0) {
-                    q = fpu;
-                    child_total = cc.n_inflight;
-                } else {
-                    q = fpu;
-                }
-                const float u = c_puct * eff_prior * sqrtf(parent_n) / (1.0f + static_cast<float>(child_total));
-                const float m_util = real ? G::aux_utility(child_m, parent_m, child_q, p) : 0.0f;
-                const float score = q + u + m_util;
-                float sc = (has && score == score) ? score : -INFINITY;
-                int si = sub;
-#pragma unroll
-                for (int o = L / 2; o > 0; o >>= 1) {
-                    const float os = __shfl_xor(sc, o, L);
-                    const int oi = __shfl_xor(si, o, L);
-                    if (os > sc || (os == sc && oi < si)) { sc = os; si = oi; }
-                }
-                best = (sc > -INFINITY) ? si : -1;
-                if (best < 0) stp = true;
-            }
-            if (!stp) {
-                ++n_levels;
-                if (depth[j] == 0) root_infl += p.vl_count;         // MCTS.h:470-475
-                const int action = __shfl(static_cast<int>(cc.meta & META_ACTION_MASK), best, L);
-                G::step(st[j], action);
-                const int res = G::result(st[j]);
-                const int child_slot = R[j].child_off + best;
-                if (sub == best) {
-                    uint32_t nm = cc.meta;
-                    if (!(nm & META_EXISTS))
-                        nm = (nm & ~META_TURN_P1) | META_EXISTS | (st[j].turn == 1 ? META_TURN_P1 : 0u);
-                    if (res >= 0)
-                        nm = (nm & ~META_RESULT_MASK) | META_TERMINAL | (static_cast<uint32_t>(res) << META_RESULT_SHIFT);
-                    cc.n_inflight += p.vl_count;                     // MCTS.h:492
-                    hot[child_slot].n_inflight = cc.n_inflight;
-                    if (nm != cc.meta) { cc.meta = nm; hot[child_slot].meta = nm; }
-                }
-                R[j] = group_bcast<L>(cc, best);
-                cur[j] = child_slot;
-                cur_lane[j] = best;
-                ++depth[j];
-                if (sub == 0) path[depth[j]] = cur[j];
-            } else {
-                uint32_t lm = R[j].meta;
-                bool term = (lm & META_TERMINAL) != 0;
-                int code = static_cast<int>((lm & META_RESULT_MASK) >> META_RESULT_SHIFT);
-                if (!term) {
-                    const int res = G::result(st[j]);
-                    if (res >= 0) {
-                        term = true; code = res;
-                        lm = (lm & ~META_RESULT_MASK) | META_TERMINAL | (static_cast<uint32_t>(res) << META_RESULT_SHIFT);
-                        if (sub == cur_lane[j]) hot[cur[j]].meta = lm;
-                        if (depth[j] == 0) rootrec.meta = lm;
-                    }
-                }
-                if (term) ++n_terminal;
-                uint8_t fl = static_cast<uint8_t>((term ? LEAF_TERMINAL : 0) | (code << LEAF_RESULT_SHIFT));
-                if (depth[j] > 0) fl |= LEAF_VL_APPLIED;
-                if (depth[j] == 0 && !(lm & META_EXPANDED)) fl |= LEAF_ROOT_UNEXPANDED;
-                if (lm & META_EXPANDED) fl |= LEAF_EXPANDED;
-                const int nv = term ? 0 : G::num_valid(st[j]);
-                if (sub == 0) lf.slot[flat] = cur[j];
-                if (sub == 1) lf.bb0[flat] = st[j].bb0;
-                if (sub == 2) lf.bb1[flat] = st[j].bb1;
-                if (sub == 3) lf.turn[flat] = st[j].turn;
-                if (sub == 4) lf.flags[flat] = fl;
-                if (sub == 5) lf.path_len[flat] = depth[j] + 1;
-                if (sub == 6) lf.aux[flat] = st[j].aux;
-                if (sub == 7) lf.nvalid[flat] = static_cast<uint8_t>(nv);
-                fin[j] = true;
-            }
-        }
-        bool all_fin = true;
-#pragma unroll
-        for (int j = 0; j < KMAX; ++j) all_fin = all_fin && fin[j];
-        if (__all(all_fin)) break;
-    }
-
-    if (live && sub == 0 && root_infl != rootrec.n_inflight) hot[root].n_inflight = root_infl;
-
-    wave_add_counter(counters, CNT_LEVELS, sub == 0 ? n_levels : 0u);
-    wave_add_counter(counters, CNT_TERMINAL, sub == 0 ? n_terminal : 0u);
-    wave_add_counter(counters, CNT_SIMS, (live && sub == 0) ? static_cast<unsigned>(K) : 0u);
-}
-
 // ------------------------------------------------------------------ selection, Connect4-shaped groups of 8 lanes
 //
 // k_select run by ONE wavefront per SIMD issues every instruction - vector or scalar - at 4 cycles, so
@@ -569,9 +366,8 @@ __global__ void __launch_bounds__(WAVE) k_select_staggered(TreeArena ar, RootSta
 //   * predicated single-lane stores (a branch each) are gathered into one block per level and one per
 //     leaf; the first 16 path entries ride in two registers per lane (lane j keeps depths j, j+8) and
 //     leave with two unconditional stores per leaf (entries past the path's end are ignored downstream);
-//   * while a level's arithmetic runs, every lane touches the first, middle and last record of ITS
-//     child's own child block, so that the block picked a few hundred cycles later is in the cache
-//     hierarchy already (the loads are issued from inline assembly: results unused).
+// (Touching the grandchildren's blocks while a level's arithmetic runs was tried and was slower: the loads
+// mostly hit L2 already and the touches only add instructions.)
 constexpr int DPP_QP0 = 0x00, DPP_QP1 = 0x55, DPP_QP2 = 0xAA, DPP_QP3 = 0xFF;     // quad_perm broadcasts of lane 0..3
 constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_QREV = 0x1B;                  // quad_perm [1,0,3,2] [2,3,0,1] [3,2,1,0]
 constexpr int DPP_HALF_MIRROR = 0x141;                                            // lane i <- lane 7 - i in each 8
@@ -619,15 +415,9 @@ __device__ __forceinline__ int group8_argmax(float score, bool valid, int lane)
     return g ? __ffs(g) - 1 : -1;
 }
 
-__device__ __forceinline__ void touch_line(const void *p, int &sink)
-{
-    asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(p));
-}
-
 template <bool VL>
 __global__ void __launch_bounds__(WAVE) k_select8(TreeArena ar, RootState rs, LeafBuf lf, SearchParams p, int K,
-                                                  int tpw, unsigned long long *counters, uint64_t *bump, long long *zero,
-                                                  int prefetch)
+                                                  int tpw, unsigned long long *counters, uint64_t *bump, long long *zero)
 {
     using G = Connect4Dev;
     constexpr int L = 8;
@@ -658,7 +448,6 @@ __global__ void __launch_bounds__(WAVE) k_select8(TreeArena ar, RootState rs, Le
     size_t flat = static_cast<size_t>(t) * K;
     int path0 = root, path1 = 0;                      // this lane's path entries: depths sub and sub + 8
     unsigned n_levels = 0, n_terminal = 0;
-    int pf0 = 0, pf1 = 0, pf2 = 0;
 
     auto is_leaf = [](uint32_t meta) {                // MCTS.h:250-258
         return !(meta & META_EXPANDED) || (meta & META_TERMINAL) || (meta & META_NEDGE_MASK) == 0;
@@ -718,16 +507,6 @@ __global__ void __launch_bounds__(WAVE) k_select8(TreeArena ar, RootState rs, Le
             if (is_root && root_mix && has) noise = cold[R.child_off + sub].noise;
             if (!has) { c.meta = 0u; c.prior = 0.0f; c.child_off = -1; }
             const bool exists = (c.meta & META_EXISTS) != 0;
-            asm volatile("" :: "v"(pf0), "v"(pf1), "v"(pf2), "v"(c.meta));     // last level's touches are older than this load
-            if (prefetch) {
-                const int cE = static_cast<int>((c.meta & META_NEDGE_MASK) >> META_NEDGE_SHIFT);
-                if ((c.meta & META_EXPANDED) && cE > 0) {
-                    const HotRec *blk = hot + c.child_off;
-                    touch_line(blk, pf0);
-                    touch_line(blk + (cE >> 1), pf1);
-                    touch_line(blk + (cE - 1), pf2);
-                }
-            }
             const bool real = exists && c.n_visits > 0;
 
             const float pq = mean_q(R.n_visits, R.w_p1, R.w_p2, (meta & META_TURN_P1) != 0);
@@ -798,8 +577,6 @@ __global__ void __launch_bounds__(WAVE) k_select8(TreeArena ar, RootState rs, Le
         }
         if (__all(done)) break;
     }
-    asm volatile("" :: "v"(pf0), "v"(pf1), "v"(pf2));
-
     if (live && VL && sub == 0 && root_infl != rootrec.n_inflight) hot[root].n_inflight = root_infl;
 
     wave_add_counter(counters, CNT_LEVELS, sub == 0 ? n_levels : 0u);
@@ -809,7 +586,7 @@ __global__ void __launch_bounds__(WAVE) k_select8(TreeArena ar, RootState rs, Le
 
 // The K <= 4 virtual-loss descents of a tree SIDE BY SIDE in one wavefront: descent j lives in its own
 // group of 8 lanes (a tree takes 32 lanes, a wavefront holds two trees) and starts j steps after
-// descent 0.  The argument for running them one level apart is k_select_staggered's: descent j + 1 meets
+// descent 0.  Why they may run one level apart: descent j + 1 meets
 // descent j only through what j leaves on a node when it ARRIVES there (in-flight visits, the EXISTS /
 // TERMINAL bits), and j arrives one step before j + 1 reads that node among its parent's children; two
 // descents of a tree are never on the same level in the same step, so they never write the same record
@@ -1916,27 +1693,19 @@ void launch_bump_call(uint64_t *call_ctr, hipStream_t s)
 void launch_select(int game, TreeArena ar, RootState rs, LeafBuf lf, SearchParams p, int K, bool vl,
                    unsigned long long *counters, hipStream_t s, uint64_t *bump_call, int64_t *zero)
 {
-    static const bool staggered = getenv("AZ_SELECT_STAGGERED") != nullptr && getenv("AZ_SELECT_STAGGERED")[0] == '1';
-    // AZ_SELECT_VARIANT: 0 = k_select (the first kernel, every game), 1 = k_select8 (Connect4) without the
-    // touches of the grandchildren blocks, 2 (default) = k_select8 with them
+    // AZ_SELECT_VARIANT: 0 = k_select (the first kernel, every game), 1 = k_select8 (Connect4) for every launch,
+    // 3 (default) = k_select8x4 for virtual-loss batches of 2..4 descents, k_select8 for the rest
     static const int variant = [] { const char *e = getenv("AZ_SELECT_VARIANT"); return e ? atoi(e) : 3; }();
-    // 3 = the K <= 4 virtual-loss descents of a tree side by side (k_select8x4); plain selections use k_select8
     if (game == Connect4Dev::GAME_ID && variant >= 3 && vl && K >= 2 && K <= 4) {
         hipLaunchKernelGGL(k_select8x4, dim3(grid_for(ar.B, 2)), dim3(WAVE), 0, s, ar, rs, lf, p, K, counters, bump_call,
                            reinterpret_cast<long long *>(zero));
         return;
     }
-    if (game == Connect4Dev::GAME_ID && variant >= 1 && !(vl && staggered)) {
+    if (game == Connect4Dev::GAME_ID && variant >= 1) {
         const int tpw = trees_per_wave(Connect4Dev::LANES);
         const dim3 grid(grid_for(ar.B, tpw)), block(WAVE);
-        if (vl) hipLaunchKernelGGL((k_select8<true>), grid, block, 0, s, ar, rs, lf, p, K, tpw, counters, bump_call, reinterpret_cast<long long *>(zero), variant == 2 ? 1 : 0);
-        else    hipLaunchKernelGGL((k_select8<false>), grid, block, 0, s, ar, rs, lf, p, K, tpw, counters, bump_call, reinterpret_cast<long long *>(zero), variant == 2 ? 1 : 0);
-        return;
-    }
-    if (vl && staggered && K >= 2 && K <= 4 && game == Connect4Dev::GAME_ID) {
-        const int tpw = trees_per_wave(Connect4Dev::LANES);
-        hipLaunchKernelGGL((k_select_staggered<Connect4Dev, 4>), dim3(grid_for(ar.B, tpw)), dim3(WAVE), 0, s, ar, rs, lf, p, K,
-                           tpw, counters, bump_call, reinterpret_cast<long long *>(zero));
+        if (vl) hipLaunchKernelGGL((k_select8<true>), grid, block, 0, s, ar, rs, lf, p, K, tpw, counters, bump_call, reinterpret_cast<long long *>(zero));
+        else    hipLaunchKernelGGL((k_select8<false>), grid, block, 0, s, ar, rs, lf, p, K, tpw, counters, bump_call, reinterpret_cast<long long *>(zero));
         return;
     }
     AZ_DISPATCH(game, {

@@ -64,7 +64,7 @@ PROFILE_EVERY = 16       # an event pair costs the stream ~5 us: six kinds of ke
 def select_kernel_name():
     """The selection kernel a virtual-loss launch runs (kernels.hip launch_select, AZ_SELECT_VARIANT)."""
     v = int(os.environ.get("AZ_SELECT_VARIANT", "3"))
-    return {0: "k_select<Connect4Dev,true>", 1: "k_select8<true>", 2: "k_select8<true>+touch"}.get(v, "k_select8x4")
+    return {0: "k_select<Connect4Dev,true>", 1: "k_select8<true>", 2: "k_select8<true>"}.get(v, "k_select8x4")
 
 
 def parse():
