@@ -1016,6 +1016,12 @@ def test_fast_othello_twin_matches_module(env):
         assert (w.get_visits_count().sum(1) == 39).all()
     st = w._fused.table_stats()
     assert w._fused.table_log2 == 18 and st["hits"] > 0.4 * st["lookups"], st      # the second search replays the first
+    w.refresh_cache(net)                                # Othello: the table is emptied (re-evaluation in place is Connect4's)
+    for i in range(200):
+        w.mcts.reset_env(i)
+    w.batch_playout(net, boards, turns, vl_batch=4, fused=True)
+    st2 = w._fused.table_stats()
+    assert st2["lookups"] > st["lookups"] and (w.get_visits_count().sum(1) == 39).all()
 
 
 def test_othello_native_model_object(env):
