@@ -26,7 +26,7 @@ def main():
     torch.manual_seed(1234)
     net = Connect4Net(device=dev).eval()
     from src.selfplay import StreamedSelfPlay
-    sp = StreamedSelfPlay(net, games, streams=P, n_playout=200, vl_batch=4, reserve_slots=49152)
+    sp = StreamedSelfPlay(net, games, streams=P, n_playout=200, vl_batch=4)
 
     def phase(n):
         sp.step(n) if JOIN == 0 else [sp.step() for _ in range(n)]

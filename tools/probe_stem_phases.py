@@ -1,3 +1,8 @@
+"""Phase shares (az_nn_debug bit 4: s_memtime stamps per wavefront) of the stem and of a residual block of the
+evaluator: P1 (tile -> normalised image in LDS), MFMA + epilogue, P3 (store) and the barriers between them.
+
+    python tools/probe_stem_phases.py
+"""
 import os, sys, runpy
 sys.argv = ["probe_nn.py", "heads", "0", "1"]
 ns = runpy.run_path(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tools", "probe_nn.py"))
