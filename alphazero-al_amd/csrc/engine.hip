@@ -201,9 +201,10 @@ struct az_mcts {
     DevBuf<int32_t> ev_rows;
     DevBuf<int64_t> ev_nrows;
     // one chunk of az_mcts_dev_tt_refresh
-    DevBuf<float> rf_feat, rf_probs, rf_wdl, rf_ml;
+    DevBuf<float> rf_probs, rf_wdl, rf_ml;
     DevBuf<uint8_t> rf_mask, rf_scratch;
-    DevBuf<int32_t> rf_rows;
+    DevBuf<uint64_t> rf_bb0, rf_bb1;
+    DevBuf<int32_t> rf_rows, rf_turn, rf_sym;
     DevBuf<int64_t> rf_count;
     DevBuf<uint64_t> rf_keys;
     bool profiling = false;
@@ -1229,28 +1230,33 @@ int az_mcts_dev_tt_refresh(az_mcts *m, const az_nn_model *model, void *stream)
         require(m->tt_entries.p != nullptr, "dev_tt_refresh: no table (az_mcts_dev_tt_create)");
         require(model != nullptr, "dev_tt_refresh: no evaluator model");
         const int kind = az_nn_model_kind(model);
-        require(m->game == AZ_GAME_CONNECT4 && (kind == AZ_NN_KIND_CONNECT4_CNN || kind == AZ_NN_KIND_HASH_CONNECT4),
-                "dev_tt_refresh: re-evaluation in place is built for Connect4 (empty an Othello table with az_mcts_dev_tt_clear)");
+        require(kind == (m->game == AZ_GAME_CONNECT4 ? AZ_NN_KIND_HASH_CONNECT4 : AZ_NN_KIND_HASH_OTHELLO) ||
+                    (kind == AZ_NN_KIND_CONNECT4_CNN && m->game == AZ_GAME_CONNECT4) ||
+                    (kind == AZ_NN_KIND_OTHELLO_CNN && m->game == AZ_GAME_OTHELLO),
+                "dev_tt_refresh: the evaluator model does not belong to this engine's game");
         HIP_OK(hipSetDevice(m->device));
         hipStream_t s = static_cast<hipStream_t>(stream);
         const int64_t chunk = 16384;
+        const int A = m->geo.actions;
         const size_t scratch = az_nn_model_scratch_bytes(model, chunk);
         if (m->rf_rows.n < static_cast<size_t>(chunk) || m->rf_scratch.n < scratch) {
             HIP_OK(hipStreamSynchronize(s));
-            m->rf_feat.ensure(chunk * 126); m->rf_mask.ensure(chunk * 7); m->rf_probs.ensure(chunk * 7);
+            m->rf_bb0.ensure(chunk); m->rf_bb1.ensure(chunk); m->rf_turn.ensure(chunk); m->rf_sym.ensure(chunk);
+            m->rf_mask.ensure(chunk * A); m->rf_probs.ensure(chunk * A);
             m->rf_wdl.ensure(chunk * 3); m->rf_ml.ensure(chunk); m->rf_rows.ensure(chunk); m->rf_keys.ensure(2 * chunk);
             m->rf_count.ensure(1, true); m->rf_scratch.ensure(scratch);
         }
         az::TtTable t{m->tt_entries.p, m->tt_mask, m->tt_stats.p};
         const int64_t entries = static_cast<int64_t>(m->tt_mask) + 1;
+        const az_nn_positions pos{m->rf_bb0.p, m->rf_bb1.p, m->rf_turn.p, m->rf_sym.p};
         for (int64_t e0 = 0; e0 < entries; e0 += chunk) {
             const int n = static_cast<int>(std::min<int64_t>(chunk, entries - e0));
-            az::launch_tt_refresh_gather(t, static_cast<uint64_t>(e0), n, m->rf_feat.p, m->rf_mask.p, m->rf_rows.p, m->rf_count.p,
-                                         m->rf_keys.p, s);
-            if (az_nn_model_forward(model, m->rf_feat.p, m->rf_mask.p, m->rf_probs.p, m->rf_wdl.p, m->rf_ml.p, n, m->rf_rows.p,
-                                    m->rf_count.p, m->rf_scratch.p, m->rf_scratch.n, stream) != 0)
-                throw AzError(AZ_ERR_ARG, "dev_tt_refresh: az_nn_model_forward refused its arguments");
-            az::launch_tt_refresh_store(t, static_cast<uint64_t>(e0), n, m->rf_rows.p, m->rf_count.p, m->rf_keys.p, m->rf_probs.p,
+            az::launch_tt_refresh_gather(m->game, t, static_cast<uint64_t>(e0), n, m->rf_bb0.p, m->rf_bb1.p, m->rf_turn.p, m->rf_sym.p,
+                                         m->rf_mask.p, m->rf_rows.p, m->rf_count.p, m->rf_keys.p, s);
+            if (az_nn_model_forward_positions(model, &pos, m->rf_mask.p, m->rf_probs.p, m->rf_wdl.p, m->rf_ml.p, n, m->rf_rows.p,
+                                              m->rf_count.p, m->rf_scratch.p, m->rf_scratch.n, stream) != 0)
+                throw AzError(AZ_ERR_ARG, "dev_tt_refresh: the evaluator model refused its arguments");
+            az::launch_tt_refresh_store(m->game, t, static_cast<uint64_t>(e0), n, m->rf_rows.p, m->rf_count.p, m->rf_keys.p, m->rf_probs.p,
                                         m->rf_wdl.p, m->rf_ml.p, s);
         }
     });

@@ -147,10 +147,10 @@ void launch_tt_lookup(int game, LeafBuf lf, int n_leaves, TtTable t, const uint6
 void launch_tt_insert(int game, int n_leaves, TtTable t, const uint64_t *clock, const int32_t *miss_idx, const int64_t *miss_count,
                       const uint64_t *keys, const float *probs, const float *wdl, const float *ml, hipStream_t s);
 
-// table refresh (MCTS_cpp.py:361-377): entries [e0, e0+n) -> evaluator inputs + compact list; fresh values -> same keys
-void launch_tt_refresh_gather(TtTable t, uint64_t e0, int n, float *features, uint8_t *mask, int32_t *rows, int64_t *count,
-                              uint64_t *keys, hipStream_t s);
-void launch_tt_refresh_store(TtTable t, uint64_t e0, int n, const int32_t *rows, const int64_t *count, const uint64_t *keys,
+// table refresh (MCTS_cpp.py:361-377): entries [e0, e0+n) -> positions + masks + compact list; fresh values -> same keys
+void launch_tt_refresh_gather(int game, TtTable t, uint64_t e0, int n, uint64_t *bb_p1, uint64_t *bb_p2, int32_t *turn, int32_t *sym,
+                              uint8_t *mask, int32_t *rows, int64_t *count, uint64_t *keys, hipStream_t s);
+void launch_tt_refresh_store(int game, TtTable t, uint64_t e0, int n, const int32_t *rows, const int64_t *count, const uint64_t *keys,
                              const float *probs, const float *wdl, const float *ml, hipStream_t s);
 
 }  // namespace az

@@ -176,8 +176,8 @@ __global__ void __launch_bounds__(256) k_tt_insert(TtTable t, int n_leaves, cons
 // reference calls after a weight update so that the table keeps its keys and loses no warmth).
 // Pass 1 decodes the entries [e0, e0 + n) - the key comes back by XORing with the value's checksum -
 // and writes, for every resident one, the evaluator's input exactly as it was when the entry was
-// made (the stored frame IS the evaluator's frame): relative planes, action mask, its row in the
-// compact list.  The evaluator runs on that list.  Pass 2 stores the fresh values under the same
+// made (the stored frame IS the evaluator's frame): the position (symmetry id 0 from here on), its
+// action mask, its row in the compact list.  The evaluator runs on that list.  Pass 2 stores the fresh values under the same
 // keys.  An entry torn by an earlier race decodes to an implausible position and is emptied.
 __device__ __forceinline__ bool plausible_c4(uint64_t own, uint64_t opp)
 {
@@ -189,30 +189,45 @@ __device__ __forceinline__ bool plausible_c4(uint64_t own, uint64_t opp)
     return ((occ + BOTTOM) & occ) == 0;                               // every column filled from the bottom, no gaps
 }
 
-__global__ void __launch_bounds__(256) k_tt_refresh_gather(TtTable t, uint64_t e0, int n, float *features, uint8_t *mask,
-                                                           int32_t *rows, int64_t *count, uint64_t *keys)
+// decode one entry's key into the position the evaluator saw (frame of the entry: symmetry id 0 from here on)
+template <class G>
+__device__ __forceinline__ bool decode_key(uint64_t k0, uint64_t k1, uint64_t &p1, uint64_t &p2, int &turn)
 {
+    if (G::GAME_ID == 0) {
+        const uint64_t own = k0 & ~(1ull << 63), opp = k1 & ~(1ull << 62);
+        if ((k1 >> 62) != 1ull || !plausible_c4(own, opp)) return false;
+        const bool first = (k0 >> 63) != 0;
+        p1 = first ? own : opp; p2 = first ? opp : own; turn = first ? 1 : -1;
+        return true;
+    }
+    // Othello: player +1 to move stores (p1, p2), player -1 stores (~p2, ~p1); stones never overlap, so the
+    // plain form has k0 & k1 == 0 and the complemented one does not (a full board is terminal: never stored)
+    if ((k0 & k1) == 0) { p1 = k0; p2 = k1; turn = 1; }
+    else { p1 = ~k1; p2 = ~k0; turn = -1; }
+    return (p1 & p2) == 0 && (p1 | p2) != 0;
+}
+
+template <class G>
+__global__ void __launch_bounds__(256) k_tt_refresh_gather(TtTable t, uint64_t e0, int n, uint64_t *bb_p1, uint64_t *bb_p2,
+                                                           int32_t *turn, int32_t *sym, uint8_t *mask, int32_t *rows,
+                                                           int64_t *count, uint64_t *keys)
+{
+    using T = Tt<G>;
     const int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     bool live = false;
-    using T = Tt<Connect4Dev>;
     if (j < n) {
         uint8_t *ent = T::entry(t, e0 + j);
         if (*T::stamp(ent) != 0) {
             const uint64_t c = T::value_sum(T::val(ent));
             const uint64_t k0 = T::key(ent)[0] ^ c, k1 = T::key(ent)[1] ^ (c << 17 | c >> 47);
-            const uint64_t own = k0 & ~(1ull << 63), opp = k1 & ~(1ull << 62);
-            if ((k1 >> 62) == 1ull && plausible_c4(own, opp)) {
+            GameState st;
+            st.aux = G::root_aux(0, 0);
+            if (decode_key<G>(k0, k1, st.bb0, st.bb1, st.turn)) {
                 live = true;
                 keys[2 * j] = k0; keys[2 * j + 1] = k1;
-                const float side = (k0 >> 63) ? 1.0f : -1.0f;
-                float *f = features + j * 126;
-                for (int cell = 0; cell < 42; ++cell) {
-                    const int bit = (cell % 7) * 7 + (5 - cell / 7);
-                    f[cell] = ((own >> bit) & 1ull) ? 1.0f : 0.0f;
-                    f[42 + cell] = ((opp >> bit) & 1ull) ? 1.0f : 0.0f;
-                    f[84 + cell] = side;
-                }
-                for (int a = 0; a < 7; ++a) mask[j * 7 + a] = (((own | opp) >> (a * 7 + 5)) & 1ull) ? 0 : 1;
+                bb_p1[j] = st.bb0; bb_p2[j] = st.bb1; turn[j] = st.turn; sym[j] = 0;
+                st.aux = G::root_aux(st.bb0, st.bb1);
+                for (int a = 0; a < G::ACTIONS; ++a) mask[j * G::ACTIONS + a] = G::valid_in_frame(st, 0, a) ? 1 : 0;
             } else {
                 *T::stamp(ent) = 0;                                   // unreadable: empty it
             }
@@ -230,21 +245,21 @@ __global__ void __launch_bounds__(256) k_tt_refresh_gather(TtTable t, uint64_t e
     }
 }
 
+template <class G>
 __global__ void __launch_bounds__(256) k_tt_refresh_store(TtTable t, uint64_t e0, int n, const int32_t *rows,
                                                           const int64_t *count, const uint64_t *keys, const float *probs,
                                                           const float *wdl, const float *ml)
 {
+    using T = Tt<G>;
     const int64_t q = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (q >= *count || q >= n) return;
     const int64_t j = rows[q];
     if (j < 0 || j >= n) return;
-    using T = Tt<Connect4Dev>;
     uint8_t *ent = T::entry(t, e0 + j);
     float *v = T::val(ent);
-#pragma unroll
-    for (int a = 0; a < 7; ++a) v[a] = probs[j * 7 + a];
-    v[7] = wdl[j * 3 + 0]; v[8] = wdl[j * 3 + 1]; v[9] = wdl[j * 3 + 2];
-    v[10] = ml[j];
+    for (int a = 0; a < T::A; ++a) v[a] = probs[j * T::A + a];
+    v[T::A] = wdl[j * 3 + 0]; v[T::A + 1] = wdl[j * 3 + 1]; v[T::A + 2] = wdl[j * 3 + 2];
+    v[T::A + 3] = ml[j];
     const uint64_t c = T::value_sum(v);
     T::key(ent)[0] = keys[2 * j] ^ c;
     T::key(ent)[1] = keys[2 * j + 1] ^ (c << 17 | c >> 47);            // the stamp - its age - is not changed by a refresh
@@ -292,17 +307,25 @@ void launch_live_leaves(LeafBuf lf, int n_leaves, int32_t *idx, int64_t *count, 
     hipLaunchKernelGGL(k_live_leaves, dim3((n_leaves + 1023) / 1024), dim3(1024), 0, s, lf, n_leaves, idx, count, err);
 }
 
-void launch_tt_refresh_gather(TtTable t, uint64_t e0, int n, float *features, uint8_t *mask, int32_t *rows, int64_t *count,
-                              uint64_t *keys, hipStream_t s)
+void launch_tt_refresh_gather(int game, TtTable t, uint64_t e0, int n, uint64_t *bb_p1, uint64_t *bb_p2, int32_t *turn, int32_t *sym,
+                              uint8_t *mask, int32_t *rows, int64_t *count, uint64_t *keys, hipStream_t s)
 {
     (void)hipMemsetAsync(count, 0, sizeof(int64_t), s);
-    hipLaunchKernelGGL(k_tt_refresh_gather, dim3((n + 255) / 256), dim3(256), 0, s, t, e0, n, features, mask, rows, count, keys);
+    const dim3 grid((n + 255) / 256), block(256);
+    if (game == Connect4Dev::GAME_ID)
+        hipLaunchKernelGGL(k_tt_refresh_gather<Connect4Dev>, grid, block, 0, s, t, e0, n, bb_p1, bb_p2, turn, sym, mask, rows, count, keys);
+    else
+        hipLaunchKernelGGL(k_tt_refresh_gather<OthelloDev>, grid, block, 0, s, t, e0, n, bb_p1, bb_p2, turn, sym, mask, rows, count, keys);
 }
 
-void launch_tt_refresh_store(TtTable t, uint64_t e0, int n, const int32_t *rows, const int64_t *count, const uint64_t *keys,
+void launch_tt_refresh_store(int game, TtTable t, uint64_t e0, int n, const int32_t *rows, const int64_t *count, const uint64_t *keys,
                              const float *probs, const float *wdl, const float *ml, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_tt_refresh_store, dim3((n + 255) / 256), dim3(256), 0, s, t, e0, n, rows, count, keys, probs, wdl, ml);
+    const dim3 grid((n + 255) / 256), block(256);
+    if (game == Connect4Dev::GAME_ID)
+        hipLaunchKernelGGL(k_tt_refresh_store<Connect4Dev>, grid, block, 0, s, t, e0, n, rows, count, keys, probs, wdl, ml);
+    else
+        hipLaunchKernelGGL(k_tt_refresh_store<OthelloDev>, grid, block, 0, s, t, e0, n, rows, count, keys, probs, wdl, ml);
 }
 
 size_t tt_entry_bytes(int game) { return game == Connect4Dev::GAME_ID ? Tt<Connect4Dev>::BYTES : Tt<OthelloDev>::BYTES; }

@@ -251,9 +251,9 @@ class FusedSearch:
             model = self._native_model()
         elif self.fast is not None and hasattr(self.fast, "native_model"):
             model = self.fast.native_model()
-        if model is not None and self.game_name == "Connect4":
+        if model is not None:
             check(lib().az_mcts_dev_tt_refresh(self.h, model, _stream()))
-        else:                                        # Othello, or an evaluator without a native model object
+        else:                                        # an evaluator without a native model object
             check(lib().az_mcts_dev_tt_clear(self.h, _stream()))
 
     def table_stats(self):

@@ -247,7 +247,7 @@ int az_mcts_dev_search(az_mcts *m, const struct az_nn_model *model, int n_playou
  * A lookup never returns a value that was not inserted for exactly its key (torn entries fail a
  * checksum and read as misses).  When the evaluator's weights change the cached outputs are stale:
  * az_mcts_dev_tt_refresh re-evaluates them in place as the reference's `refresh_cache` does
- * (MCTS_cpp.py:361-377; Connect4), az_mcts_dev_tt_clear empties the table.
+ * (MCTS_cpp.py:361-377; both games), az_mcts_dev_tt_clear empties the table.
  * Statistics (synchronises): lookups, hits, inserts, entries replaced. */
 int az_mcts_dev_tt_create(az_mcts *m, int log2_entries);
 int az_mcts_dev_tt_clear(az_mcts *m, void *stream);

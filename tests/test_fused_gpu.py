@@ -1016,12 +1016,78 @@ def test_fast_othello_twin_matches_module(env):
         assert (w.get_visits_count().sum(1) == 39).all()
     st = w._fused.table_stats()
     assert w._fused.table_log2 == 18 and st["hits"] > 0.4 * st["lookups"], st      # the second search replays the first
-    w.refresh_cache(net)                                # Othello: the table is emptied (re-evaluation in place is Connect4's)
+    w.refresh_cache(net)                                # same weights: every resident key re-evaluated in place
     for i in range(200):
         w.mcts.reset_env(i)
     w.batch_playout(net, boards, turns, vl_batch=4, fused=True)
     st2 = w._fused.table_stats()
     assert st2["lookups"] > st["lookups"] and (w.get_visits_count().sum(1) == 39).all()
+
+
+def test_othello_table_refresh_in_place(env):
+    """`refresh_cache` (MCTS_cpp.py:361-377) for an Othello table: after a weight update every resident
+    key - the leaf as the evaluator saw it, decoded back from the entry - is evaluated again by the
+    native model and stored under the same key.  The native evaluator is a pure function per row, so
+    a search served from the refreshed table must equal, bit for bit, a search with the new weights
+    and no table; the same table NOT refreshed must not (the check can fail)."""
+    os.environ["AZ_FUSED_GRAPH"] = "0"               # below 512 trees too: the native loop, with and without the table
+    try:
+        _othello_table_refresh(env)
+    finally:
+        os.environ.pop("AZ_FUSED_GRAPH", None)
+
+
+def _othello_table_refresh(env):
+    torch = env["torch"]
+    net = _rand_othello_net(env, 5)
+    rng = np.random.default_rng(77)
+    boards, turns = S.ot_openings(rng, 128, 34, 0)
+    boards[:32] = boards[0]; turns[:32] = turns[0]
+
+    def wrapper(cache):
+        w = env["W"].BatchedMCTS(128, 1.4, 1000, 0.3, 48, noise_epsilon=0.25, fpu_reduction=0.2, use_symmetry=True,
+                                 game_name="Othello", score_utility_factor=0.15, score_scale=8.0, cache_size=cache)
+        w.seed(21)
+        return w
+
+    def search(w):
+        w.batch_playout(net, boards, turns, vl_batch=4, fused=True)
+        return w.get_visits_count().copy(), bits(np.array(w.mcts.get_all_root_stats()))
+
+    tabled, stale = wrapper(200000), wrapper(200000)
+    for w in (tabled, stale):
+        search(w)                                                   # fills both tables with the OLD weights' outputs
+        assert w._fused.table_log2 == 18 and w._fused.table_stats()["inserts"] > 0
+        assert w._fused._native_model() is not None                 # the native loop and the native model are what ran
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(1.05)
+    plain = wrapper(0)
+    c0, s0 = search(plain)
+    assert plain._fused._native_model() is not None
+    cf, sf = search(wrapper(200000))                                # a table filled with the new weights' outputs from the start
+    assert np.array_equal(c0, cf) and np.array_equal(s0, sf)
+    # refreshed: the wrapper notices the new weights and re-evaluates the resident keys
+    before = tabled._fused.table_stats()
+    for i in range(128):
+        tabled.reset_env(i)
+    tabled.seed(21)
+    tabled.refresh_cache(net)
+    c1, s1 = search(tabled)
+    after = tabled._fused.table_stats()
+    assert np.array_equal(c0, c1) and np.array_equal(s0, s1)
+    assert after["hits"] - before["hits"] > 0.3 * (after["lookups"] - before["lookups"]), (before, after)
+    # not refreshed: new weights snapshotted behind the table's back - old outputs are served and the search differs
+    fs = stale._fused
+    fs.fast = None; fs._fast_version = None
+    log2, fs.table_log2 = fs.table_log2, 0
+    fs._sync_fast_net()
+    fs.table_log2 = log2
+    for i in range(128):
+        stale.reset_env(i)
+    stale.seed(21)
+    c2, s2 = search(stale)
+    assert not np.array_equal(s0, s2)
 
 
 def test_othello_native_model_object(env):
