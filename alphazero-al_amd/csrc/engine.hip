@@ -255,15 +255,18 @@ struct az_mcts {
         }
         // logf through the host libm, float arithmetic in the reference's order (MCTS.h:213-214)
         if (tab.p && cfg.c_init == tab_c_init && cfg.c_base == tab_c_base) return;
-        std::vector<float> h(kCpuctTab);
+        // second half: sqrtf(parent_n) - correctly rounded on either side, tabulated to take ~17 instructions
+        // out of a level of the Connect4 selection kernels
+        std::vector<float> h(2 * kCpuctTab);
         const float c_init = cfg.c_init, c_base = cfg.c_base;
         for (int n = 0; n < kCpuctTab; ++n) {
             const float parent_n = static_cast<float>(n);
             h[n] = c_init + std::log((parent_n + c_base + 1.0f) / c_base);
+            h[kCpuctTab + n] = std::sqrt(parent_n);
         }
         if (!tab.p) ++epoch;
-        tab.ensure(kCpuctTab);
-        HIP_OK(hipMemcpy(tab.p, h.data(), sizeof(float) * kCpuctTab, hipMemcpyHostToDevice));
+        tab.ensure(2 * kCpuctTab);
+        HIP_OK(hipMemcpy(tab.p, h.data(), sizeof(float) * 2 * kCpuctTab, hipMemcpyHostToDevice));
         tab_c_init = c_init; tab_c_base = c_base;
     }
 

@@ -19,7 +19,8 @@ struct SearchParams {
     int   use_symmetry;
     // c_puct(parent_n) = c_init + logf((parent_n + c_base + 1)/c_base) for parent_n < tab_n,
     // tabulated by the HOST libm so that the device takes the same branch the reference's
-    // logf takes (MCTS.h:213-214).
+    // logf takes (MCTS.h:213-214).  cpuct_tab[tab_n + parent_n] = sqrtf(parent_n) (exact on both sides; a load
+    // instead of the refinement sequence).
     const float *cpuct_tab;
     int   tab_n;
     // Othello terminal_aux = atanf(diff*turn / score_scale) * (2/pi) (Othello.h:260-266) for

@@ -444,6 +444,10 @@ __global__ void __launch_bounds__(WAVE) k_select8(TreeArena ar, RootState rs, Le
     bool done = !live;
     int cur = root, cur_lane = 0, depth = 0;
     HotRec R = rootrec;
+    // the root's own means (MCTSNode.h:116-133): selection changes neither visits nor sums, so once per launch
+    const float root_q = mean_q(rootrec.n_visits, rootrec.w_p1, rootrec.w_p2, (rootrec.meta & META_TURN_P1) != 0);
+    const float root_m = mean_m(rootrec.n_visits, rootrec.m_sum);
+    float Rq = root_q, Rm = root_m;
     GameState st = rstate;
     size_t flat = static_cast<size_t>(t) * K;
     int path0 = root, path1 = 0;                      // this lane's path entries: depths sub and sub + 8
@@ -488,6 +492,7 @@ __global__ void __launch_bounds__(WAVE) k_select8(TreeArena ar, RootState rs, Le
             ++flat;
             cur = root; cur_lane = 0; depth = 0;
             R = rootrec; R.n_inflight = root_infl;
+            Rq = root_q; Rm = root_m;
             st = rstate;
             path0 = root;                                              // depth 0 in lane 0; the others are overwritten on the way
         }
@@ -509,7 +514,7 @@ __global__ void __launch_bounds__(WAVE) k_select8(TreeArena ar, RootState rs, Le
             const bool exists = (c.meta & META_EXISTS) != 0;
             const bool real = exists && c.n_visits > 0;
 
-            const float pq = mean_q(R.n_visits, R.w_p1, R.w_p2, (meta & META_TURN_P1) != 0);
+            const float pq = Rq;                      // mean_q / mean_m of R: computed when R was a candidate one level up
             const float seen = group8_ordered_sum7(real ? c.prior : 0.0f);
             const float scale = (1.0f + pq) / 2.0f;
             const float eff = p.fpu_reduction * scale;
@@ -518,10 +523,10 @@ __global__ void __launch_bounds__(WAVE) k_select8(TreeArena ar, RootState rs, Le
 
             const int pn_i = R.n_visits + R.n_inflight;
             const float parent_n = static_cast<float>(pn_i);
-            const float parent_m = mean_m(R.n_visits, R.m_sum);
-            const float c_puct = (pn_i >= 0 && pn_i < p.tab_n)
-                ? p.cpuct_tab[pn_i]
-                : p.c_init + logf((parent_n + p.c_base + 1.0f) / p.c_base);
+            const float parent_m = Rm;
+            const bool in_tab = pn_i >= 0 && pn_i < p.tab_n;
+            const float c_puct = in_tab ? p.cpuct_tab[pn_i] : p.c_init + logf((parent_n + p.c_base + 1.0f) / p.c_base);
+            const float sqrt_pn = in_tab ? p.cpuct_tab[p.tab_n + pn_i] : sqrtf(parent_n);
             float eff_prior = c.prior;
             if (is_root && root_mix) eff_prior = fmaf(c.prior, 1.0f - ne, ne * noise);
 
@@ -533,7 +538,7 @@ __global__ void __launch_bounds__(WAVE) k_select8(TreeArena ar, RootState rs, Le
                 child_m = mean_m(c.n_visits, c.m_sum);
                 q = -child_q;
             }
-            const float u = c_puct * eff_prior * sqrtf(parent_n) / (1.0f + static_cast<float>(child_total));
+            const float u = c_puct * eff_prior * sqrt_pn / (1.0f + static_cast<float>(child_total));
             const float m_util = real ? G::aux_utility(child_m, parent_m, child_q, p) : 0.0f;
             const float score = q + u + m_util;
             const int best = group8_argmax(score, has && score == score, lane);
@@ -550,6 +555,8 @@ __global__ void __launch_bounds__(WAVE) k_select8(TreeArena ar, RootState rs, Le
                 const float b_w1 = __shfl(c.w_p1, src);
                 const float b_w2 = __shfl(c.w_p2, src);
                 const float b_ms = __shfl(c.m_sum, src);
+                Rq = __shfl(child_q, src);             // 0 without real visits, as mean_q / mean_m of such a node are
+                Rm = __shfl(child_m, src);
                 G::step(st, static_cast<int>(bmeta & META_ACTION_MASK));
                 const int res = G::result(st);
                 uint32_t nm = bmeta;
@@ -623,6 +630,8 @@ __global__ void __launch_bounds__(WAVE) k_select8x4(TreeArena ar, RootState rs, 
     bool passed_root = false;                         // this descent left the root with a chosen edge (MCTS.h:470-475)
     int cur = root, cur_lane = 0, depth = 0;
     HotRec R = rootrec;
+    float Rq = mean_q(rootrec.n_visits, rootrec.w_p1, rootrec.w_p2, (rootrec.meta & META_TURN_P1) != 0);   // see k_select8
+    float Rm = mean_m(rootrec.n_visits, rootrec.m_sum);
     const size_t flat = static_cast<size_t>(t) * K + (j < K ? j : 0);
     int path0 = root, path1 = 0;                      // this lane's path entries: depths sub and sub + 8
     unsigned n_levels = 0, n_terminal = 0;
@@ -682,7 +691,7 @@ __global__ void __launch_bounds__(WAVE) k_select8x4(TreeArena ar, RootState rs, 
             const bool exists = (c.meta & META_EXISTS) != 0;
             const bool real = exists && c.n_visits > 0;
 
-            const float pq = mean_q(R.n_visits, R.w_p1, R.w_p2, (meta & META_TURN_P1) != 0);
+            const float pq = Rq;                      // mean_q / mean_m of R: computed when R was a candidate one level up
             const float seen = group8_ordered_sum7(real ? c.prior : 0.0f);
             const float scale = (1.0f + pq) / 2.0f;
             const float eff = p.fpu_reduction * scale;
@@ -691,10 +700,10 @@ __global__ void __launch_bounds__(WAVE) k_select8x4(TreeArena ar, RootState rs, 
 
             const int pn_i = R.n_visits + R.n_inflight;
             const float parent_n = static_cast<float>(pn_i);
-            const float parent_m = mean_m(R.n_visits, R.m_sum);
-            const float c_puct = (pn_i >= 0 && pn_i < p.tab_n)
-                ? p.cpuct_tab[pn_i]
-                : p.c_init + logf((parent_n + p.c_base + 1.0f) / p.c_base);
+            const float parent_m = Rm;
+            const bool in_tab = pn_i >= 0 && pn_i < p.tab_n;
+            const float c_puct = in_tab ? p.cpuct_tab[pn_i] : p.c_init + logf((parent_n + p.c_base + 1.0f) / p.c_base);
+            const float sqrt_pn = in_tab ? p.cpuct_tab[p.tab_n + pn_i] : sqrtf(parent_n);
             float eff_prior = c.prior;
             if (is_root && root_mix) eff_prior = fmaf(c.prior, 1.0f - ne, ne * noise);
 
@@ -706,7 +715,7 @@ __global__ void __launch_bounds__(WAVE) k_select8x4(TreeArena ar, RootState rs, 
                 child_m = mean_m(c.n_visits, c.m_sum);
                 q = -child_q;
             }
-            const float u = c_puct * eff_prior * sqrtf(parent_n) / (1.0f + static_cast<float>(child_total));
+            const float u = c_puct * eff_prior * sqrt_pn / (1.0f + static_cast<float>(child_total));
             const float m_util = real ? G::aux_utility(child_m, parent_m, child_q, p) : 0.0f;
             const float score = q + u + m_util;
             const int best = group8_argmax(score, has && score == score, lane);
@@ -722,6 +731,8 @@ __global__ void __launch_bounds__(WAVE) k_select8x4(TreeArena ar, RootState rs, 
                 const float b_w1 = __shfl(c.w_p1, src);
                 const float b_w2 = __shfl(c.w_p2, src);
                 const float b_ms = __shfl(c.m_sum, src);
+                Rq = __shfl(child_q, src);             // 0 without real visits, as mean_q / mean_m of such a node are
+                Rm = __shfl(child_m, src);
                 G::step(st, static_cast<int>(bmeta & META_ACTION_MASK));
                 const int res = G::result(st);
                 uint32_t nm = bmeta;
