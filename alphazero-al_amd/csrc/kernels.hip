@@ -635,6 +635,8 @@ __global__ void __launch_bounds__(WAVE) k_select8x4(TreeArena ar, RootState rs, 
     const size_t flat = static_cast<size_t>(t) * K + (j < K ? j : 0);
     int path0 = root, path1 = 0;                      // this lane's path entries: depths sub and sub + 8
     unsigned n_levels = 0, n_terminal = 0;
+    HotRec cpre = rootrec;                            // lane's record of R's children block, when have_pre
+    bool have_pre = false;
 
     auto is_leaf = [](uint32_t meta) {                // MCTS.h:250-258
         return !(meta & META_EXPANDED) || (meta & META_TERMINAL) || (meta & META_NEDGE_MASK) == 0;
@@ -684,7 +686,8 @@ __global__ void __launch_bounds__(WAVE) k_select8x4(TreeArena ar, RootState rs, 
             const int E = static_cast<int>((meta & META_NEDGE_MASK) >> META_NEDGE_SHIFT);
             const bool has = sub < E;
             const bool is_root = depth == 0;
-            HotRec c = hot[R.child_off + (has ? sub : 0)];
+            HotRec c = cpre;                          // requested while the previous step finished (below) ...
+            if (!have_pre) c = hot[R.child_off + (has ? sub : 0)];    // ... except at the root
             float noise = 0.0f;
             if (is_root && root_mix && has) noise = cold[R.child_off + sub].noise;
             if (!has) { c.meta = 0u; c.prior = 0.0f; c.child_off = -1; }
@@ -733,18 +736,31 @@ __global__ void __launch_bounds__(WAVE) k_select8x4(TreeArena ar, RootState rs, 
                 const float b_ms = __shfl(c.m_sum, src);
                 Rq = __shfl(child_q, src);             // 0 without real visits, as mean_q / mean_m of such a node are
                 Rm = __shfl(child_m, src);
-                G::step(st, static_cast<int>(bmeta & META_ACTION_MASK));
-                const int res = G::result(st);
-                uint32_t nm = bmeta;
-                if (!(nm & META_EXISTS))                                       // lazy child, MCTS.h:268-275
-                    nm = (nm & ~META_TURN_P1) | META_EXISTS | (st.turn == 1 ? META_TURN_P1 : 0u);
-                if (res >= 0)                                                  // MCTS.h:279-288
-                    nm = (nm & ~META_RESULT_MASK) | META_TERMINAL | (static_cast<uint32_t>(res) << META_RESULT_SHIFT);
-                const int n_infl = b_infl + p.vl_count;                        // MCTS.h:492
+                // What the tree's next descent must find on this node when it scores it one step from now goes
+                // out first: the in-flight visits (MCTS.h:492) and, for a lazy child, EXISTS + the side to move
+                // (MCTS.h:268-275; a Connect4 move always hands the turn over).  Then the node's own children are
+                // requested - an expanded node is never terminal, so the descent does go on there - and the move,
+                // the four-in-a-row test and the path bookkeeping below run while that load is in flight.
+                const int n_infl = b_infl + p.vl_count;
                 const int child_slot = R.child_off + best;
+                uint32_t nm = bmeta;
+                if (!(nm & META_EXISTS)) nm = (nm & ~META_TURN_P1) | META_EXISTS | (st.turn == -1 ? META_TURN_P1 : 0u);
                 if (sub == best) {
                     hot[child_slot].n_inflight = n_infl;
                     if (nm != bmeta) hot[child_slot].meta = nm;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");         // compiler only: the stores stay above the load
+                have_pre = (bmeta & META_EXPANDED) != 0 && (bmeta & META_NEDGE_MASK) != 0;
+                if (have_pre) {
+                    const int e_next = static_cast<int>((bmeta & META_NEDGE_MASK) >> META_NEDGE_SHIFT);
+                    cpre = hot[b_off + (sub < e_next ? sub : 0)];
+                }
+                G::step(st, static_cast<int>(bmeta & META_ACTION_MASK));
+                const int res = G::result(st);
+                if (res >= 0) {                                                // MCTS.h:279-288
+                    const uint32_t tm = (nm & ~META_RESULT_MASK) | META_TERMINAL | (static_cast<uint32_t>(res) << META_RESULT_SHIFT);
+                    if (sub == best && tm != nm) hot[child_slot].meta = tm;
+                    nm = tm;
                 }
                 R.n_visits = b_n; R.n_inflight = n_infl; R.w_p1 = b_w1; R.w_p2 = b_w2; R.m_sum = b_ms;
                 R.child_off = b_off; R.meta = nm;
