@@ -35,12 +35,13 @@ struct Connect4Dev {
 
     __host__ __device__ static bool four(uint64_t b)               // Connect4.h:182-203
     {
-        uint64_t t;
-        t = b & (b >> 1); if (t & (t >> 2)) return true;
-        t = b & (b >> 7); if (t & (t >> 14)) return true;
-        t = b & (b >> 6); if (t & (t >> 12)) return true;
-        t = b & (b >> 8); if (t & (t >> 16)) return true;
-        return false;
+        // all four directions, one test: on the device an early return per direction is a branch per direction
+        uint64_t t, r;
+        t = b & (b >> 1); r = t & (t >> 2);
+        t = b & (b >> 7); r |= t & (t >> 14);
+        t = b & (b >> 6); r |= t & (t >> 12);
+        t = b & (b >> 8); r |= t & (t >> 16);
+        return r != 0;
     }
     // last mover from piece parity, as import_board derives it (Connect4.h:124-128)
     __host__ __device__ static int root_aux(uint64_t bb0, uint64_t bb1)

@@ -524,9 +524,14 @@ __global__ void __launch_bounds__(WAVE) k_select8(TreeArena ar, RootState rs, Le
             const int pn_i = R.n_visits + R.n_inflight;
             const float parent_n = static_cast<float>(pn_i);
             const float parent_m = Rm;
-            const bool in_tab = pn_i >= 0 && pn_i < p.tab_n;
-            const float c_puct = in_tab ? p.cpuct_tab[pn_i] : p.c_init + logf((parent_n + p.c_base + 1.0f) / p.c_base);
-            const float sqrt_pn = in_tab ? p.cpuct_tab[p.tab_n + pn_i] : sqrtf(parent_n);
+            // both table entries by one unconditional pair of loads (index 0 outside the table, then the formulas)
+            const bool in_tab = static_cast<unsigned>(pn_i) < static_cast<unsigned>(p.tab_n);
+            const float *tab = p.cpuct_tab + (in_tab ? pn_i : 0);
+            float c_puct = tab[0], sqrt_pn = tab[p.tab_n];
+            if (!in_tab) {
+                c_puct = p.c_init + logf((parent_n + p.c_base + 1.0f) / p.c_base);
+                sqrt_pn = sqrtf(parent_n);
+            }
             float eff_prior = c.prior;
             if (is_root && root_mix) eff_prior = fmaf(c.prior, 1.0f - ne, ne * noise);
 
@@ -704,9 +709,14 @@ __global__ void __launch_bounds__(WAVE) k_select8x4(TreeArena ar, RootState rs, 
             const int pn_i = R.n_visits + R.n_inflight;
             const float parent_n = static_cast<float>(pn_i);
             const float parent_m = Rm;
-            const bool in_tab = pn_i >= 0 && pn_i < p.tab_n;
-            const float c_puct = in_tab ? p.cpuct_tab[pn_i] : p.c_init + logf((parent_n + p.c_base + 1.0f) / p.c_base);
-            const float sqrt_pn = in_tab ? p.cpuct_tab[p.tab_n + pn_i] : sqrtf(parent_n);
+            // both table entries by one unconditional pair of loads (index 0 outside the table, then the formulas)
+            const bool in_tab = static_cast<unsigned>(pn_i) < static_cast<unsigned>(p.tab_n);
+            const float *tab = p.cpuct_tab + (in_tab ? pn_i : 0);
+            float c_puct = tab[0], sqrt_pn = tab[p.tab_n];
+            if (!in_tab) {
+                c_puct = p.c_init + logf((parent_n + p.c_base + 1.0f) / p.c_base);
+                sqrt_pn = sqrtf(parent_n);
+            }
             float eff_prior = c.prior;
             if (is_root && root_mix) eff_prior = fmaf(c.prior, 1.0f - ne, ne * noise);
 
