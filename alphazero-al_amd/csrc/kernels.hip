@@ -673,10 +673,11 @@ __global__ void __launch_bounds__(WAVE) k_select8x4(TreeArena ar, RootState rs, 
             lf.flags[flat] = fl; lf.path_len[flat] = depth + 1; lf.aux[flat] = st.aux;
             lf.nvalid[flat] = static_cast<uint8_t>(nv);
         }
-        done = true;
     };
+    // A group runs ONE descent, and what it found stays in its registers once it is done: the leaf is written
+    // out after the loop, once per wavefront, instead of in every step in which some group arrives somewhere.
 
-    if (!done && is_leaf(R.meta)) emit();             // a root that is a leaf: every descent ends where it starts
+    if (!done && is_leaf(R.meta)) done = true;        // a root that is a leaf: every descent ends where it starts
 
     for (int step = 0;; ++step) {
         // descents of this tree that have left the root already, below this one (their in-flight visits are on it)
@@ -781,11 +782,12 @@ __global__ void __launch_bounds__(WAVE) k_select8x4(TreeArena ar, RootState rs, 
                 else if (depth < 16) { if (sub == depth - 8) path1 = cur; }
                 else if (sub == 0) lf.path[flat * G::MAX_PATH + depth] = cur;
             }
-            if (best < 0 || is_leaf(R.meta)) emit();
+            if (best < 0 || is_leaf(R.meta)) done = true;                      // the node itself is the leaf (MCTS.h:250-258)
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         if (__all(done)) break;
     }
+    if (live) emit();
 
     // in-flight visits of the root: one per descent that left it (MCTS.h:470-475)
     {
