@@ -257,6 +257,19 @@ __global__ void __launch_bounds__(256, 2) k_conv_block(const uint16_t *x, const 
             tl = now;
         }
     };
+    // where this lane's vectors of its sample go in the padded, swizzled image: six dividing address chains that
+    // do not depend on the tile - kept in registers across the tile loop (the rest of P1's and P3's lane
+    // arithmetic is cheap and is recomputed per tile, see lane_t below)
+    uint32_t img_off[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int sl = lane + 64 * i;
+        const int cell = sl / VPC;
+        const int r = cell / COLS, c = cell - r * COLS;
+        const int p = (r + 1) * PCOLS + (c + 1);
+        const int ck = (lane % VPC) ^ swz_in(lane / VPC);
+        img_off[i] = static_cast<uint32_t>((wave * PCELLS + p) * CELLB + ((ck ^ (p & 7)) << 4));
+    }
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, par ^= 1) {
         const int64_t b0 = tile * TS;
         uint8_t *rawt = rawb + par * TS * SB;
@@ -328,9 +341,6 @@ __global__ void __launch_bounds__(256, 2) k_conv_block(const uint16_t *x, const 
             for (int i = 0; i < PER; ++i) {
                 const int s = lane_t + 64 * i;
                 if (s < VPS) {
-                    const int cell = s / VPC;
-                    const int r = cell / COLS, c = cell - r * COLS;
-                    const int p = (r + 1) * PCOLS + (c + 1);
                     V8 out = raw[i];
                     if (NORM) {
 #pragma unroll
@@ -339,7 +349,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_block(const uint16_t *x, const 
                             out.w[q] = pack2(f.x, f.y);
                         }
                     }
-                    *reinterpret_cast<V8 *>(img + (wave * PCELLS + p) * CELLB + ((ck ^ (p & 7)) << 4)) = out;
+                    *reinterpret_cast<V8 *>(img + img_off[i]) = out;
                 }
             }
         }
@@ -359,9 +369,13 @@ __global__ void __launch_bounds__(256, 2) k_conv_block(const uint16_t *x, const 
         // consecutive - every B-fragment read is bank-conflict free and needs no division.
         // The loop is software pipelined by one tile: the epilogue of tile i-1 (VALU) is issued
         // inside the MFMA stream of tile i, where an MFMA leaves half of its 16 issue cycles free.
-        auto tile_cols = [&](int it, uint32_t (&col)[3][KPT]) {
-            const int smp = 2 * th + it / 3;
-            const uint32_t pc = static_cast<uint32_t>(smp * PCELLS + (it % 3) * 16 + l15 + 9 - PCOLS - 1);   // row above, dx = -1
+        // Token tile `it` of this wave's pair of samples starts (it / 3) * PCELLS + (it % 3) * 16 cells after
+        // tile 0 - a multiple of 8 either way, so the swizzle key (cell & 7) of a lane's cell is the same in
+        // every tile and its byte offset differs by a CONSTANT: the three column offsets are computed once
+        // per 4-sample tile and every fragment read carries tile and row displacement in its offset field.
+        uint32_t col[3][KPT];
+        {
+            const uint32_t pc = static_cast<uint32_t>(2 * th * PCELLS + l15 + 9 - PCOLS - 1);   // row above, dx = -1
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
                 const uint32_t p = pc + d;
@@ -369,12 +383,13 @@ __global__ void __launch_bounds__(256, 2) k_conv_block(const uint16_t *x, const 
 #pragma unroll
                 for (int ks = 0; ks < KPT; ++ks) col[d][ks] = o ^ (ks << 6);
             }
-        };
-        auto fetch = [&](const uint32_t (&col)[3][KPT], int tap, bf16x8 (&xf)[KPT]) {
+        }
+        auto fetch = [&](int it, int tap, bf16x8 (&xf)[KPT]) {
             const int dy = tap / 3, d = tap % 3;
+            const int disp = (dy * PCOLS + (it / 3) * PCELLS + (it % 3) * 16) * CELLB;
 #pragma unroll
             for (int ks = 0; ks < KPT; ++ks)
-                xf[ks] = *reinterpret_cast<const bf16x8 *>(&smem[col[d][ks] + dy * PCOLS * CELLB]);   // img = smem + 0
+                xf[ks] = *reinterpret_cast<const bf16x8 *>(&smem[col[d][ks] + disp]);   // img = smem + 0
         };
         // Epilogue of one token tile on its accumulators, cut into 36 single-instruction steps so
         // that it can be issued INSIDE the next tile's MFMA stream.  This lane holds channels
@@ -415,20 +430,18 @@ __global__ void __launch_bounds__(256, 2) k_conv_block(const uint16_t *x, const 
         // scheduling barriers pin that order: a wave issues in order, so a VALU instruction
         // hides in an MFMA's free issue cycles only if it sits right behind it in the stream.
         auto block = [&](int it, f32x4 (&acc)[2], bool with_epi, const f32x4 (&pacc)[2]) {
-            uint32_t col[3][KPT];
-            tile_cols(it, col);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) acc[mt] = f32x4{bia[mt][0], bia[mt][1], bia[mt][2], bia[mt][3]};
             Epi e;
             if (with_epi) epi_begin(it - 1, e);
             bf16x8 xa[KPT], xb[KPT];
-            fetch(col, 0, xa);
+            fetch(it, 0, xa);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 bf16x8 (&cur)[KPT] = (tap & 1) ? xb : xa;
                 bf16x8 (&nxt)[KPT] = (tap & 1) ? xa : xb;
-                if (tap + 1 < 9) fetch(col, tap + 1, nxt);
+                if (tap + 1 < 9) fetch(it, tap + 1, nxt);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ks = 0; ks < KPT; ++ks)
@@ -451,12 +464,12 @@ __global__ void __launch_bounds__(256, 2) k_conv_block(const uint16_t *x, const 
         if (!(dbg & 1)) {
             f32x4 acc_a[2], acc_b[2];
             block(0, acc_a, false, acc_b);
-#pragma unroll 1
-            for (int it = 1; it < 6; it += 2) {
-                // two tiles per trip so that the accumulator sets alternate without copies
-                block(it, acc_b, true, acc_a);
-                if (it + 1 < 6) block(it + 1, acc_a, true, acc_b);
-            }
+            // unrolled: the tile number is a constant in every read's offset field; the accumulator sets alternate
+            block(1, acc_b, true, acc_a);
+            block(2, acc_a, true, acc_b);
+            block(3, acc_b, true, acc_a);
+            block(4, acc_a, true, acc_b);
+            block(5, acc_b, true, acc_a);
             {   // drain: the last tile's epilogue on its own
                 Epi e;
                 epi_begin(5, e);
