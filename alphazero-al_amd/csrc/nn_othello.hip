@@ -65,8 +65,16 @@ __global__ void __launch_bounds__(256, 2) k_oth_conv(const uint16_t *x, const ui
     constexpr int T = (NT + 15) / 16;         // token tiles
     constexpr int CELLB = CIN * 2;            // bytes per image cell
     constexpr int CPC = CIN / 8;              // 16-byte chunks per cell
-    constexpr int KEYM = CPC < 16 ? CPC - 1 : 15;
     constexpr int KPT = CIN / 32;             // k steps per tap
+    // The image is LINEAR in LDS - no XOR swizzle - so that a fragment's address is one per-lane base plus a
+    // constant: byte(row, col, chunk) = row * ROWP + col * CELLP + chunk * 16.  CELLP = one chunk more than a
+    // cell: consecutive cells sit an odd number of 16-byte slots apart, so the 16 lanes of a read (16 consecutive
+    // tokens, the same chunk of 16 cells) cover all 64 banks.  ROWP = PW cells plus what makes a step from the
+    // last token of an output row to the first of the next one (PW - HO = 2 cells further) look like one more
+    // cell to the banks: (2 * CELLP + pad) % 256 == 0.  Tap (ky, kx) and k step kc are then the CONSTANT
+    // ky * ROWP + kx * CELLP + kc * 64 in the read's offset field.
+    constexpr int CELLP = CELLB + 16;
+    constexpr int ROWP = PW * CELLP + (256 - (2 * CELLP) % 256) % 256;
     constexpr int KS = 9 * KPT;
     static_assert(!RES || PAD == 1, "the residual has the output's geometry");
     static_assert(256 % CPC == 0, "a thread keeps its channel chunk over the copy loop");
@@ -75,20 +83,15 @@ __global__ void __launch_bounds__(256, 2) k_oth_conv(const uint16_t *x, const ui
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, tl = lane & 15;
 
-    // top-left cell of every token's window in the padded image
+    // byte address of this lane's chunk (k group g) in the top-left cell of every token's window
     int cell0[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         int token = t * 16 + tl;
-        token = token < NT ? token : NT - 1;
-        cell0[t] = (token / HO) * PW + (token % HO);
+        token = token < NT ? token : NT - 1;         // the clamped tail of the last tile repeats its last token
+        cell0[t] = (token / HO) * ROWP + (token % HO) * CELLP + g * 16;
     }
-    // Swizzle key of image cell (row, col): (row * HO + col) & KEYM.  A token's window cell under tap
-    // (ky, kx) then has key (token + HO * ky + kx) & KEYM: the 16 consecutive tokens of a tile read 16
-    // distinct bank slots under every tap (keyed by the padded cell index, tokens that wrap to the next
-    // image row collided with the first ones of the tile).  Only the clamped tail of the last tile repeats.
-    const int tl_last = ((T - 1) * 16 + tl < NT ? tl : NT - 1) & 15;
-    const uint16_t *wlane = wp + static_cast<size_t>(wave * 4) * 512 + lane * 8;
+    const int wlane_off = (wave * 4) * 512 + lane * 8;           // this lane's place in a k step's 16 weight fragments
 
     for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
         // ---- copy: sample -> zero-padded, swizzled image (the BatchNorm in front of the convolution rides here)
@@ -131,7 +134,7 @@ __global__ void __launch_bounds__(256, 2) k_oth_conv(const uint16_t *x, const ui
                         wv[j] = pack2(bf_lo(wv[j]) * ps[2 * j] + pb[2 * j], bf_hi(wv[j]) * ps[2 * j + 1] + pb[2 * j + 1]);
                 }
                 if (base + k < ITERS && v < NV)
-                    *reinterpret_cast<uint4 *>(smem + cell * CELLB + ((c ^ (((cell / PW) * HO + cell % PW) & KEYM)) << 4)) = val;
+                    *reinterpret_cast<uint4 *>(smem + (cell / PW) * ROWP + (cell % PW) * CELLP + (c << 4)) = val;
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -145,17 +148,9 @@ __global__ void __launch_bounds__(256, 2) k_oth_conv(const uint16_t *x, const ui
             for (int t = 0; t < T; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
         auto fetch_a = [&](bf16x8 (&a)[4], int ks) {
             if (dbg & 1) ks &= 1;       // timing experiment (AZ_OTH_DEBUG=1, results wrong): the weight stream stays in L1
+            const uint16_t *wk = wp + static_cast<size_t>(ks) * (16 * 512);      // wave-uniform base, lane offset, constant
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                a[i] = *reinterpret_cast<const bf16x8 *>(wlane + static_cast<size_t>(ks) * (16 * 512) + i * 512);
-        };
-        auto fetch_b = [&](bf16x8 (&bq)[T], int tapcell, int tapkey, int kc) {
-#pragma unroll
-            for (int t = 0; t < T; ++t) {
-                const int p = cell0[t] + tapcell;
-                const int key = ((t == T - 1 ? tl_last : tl) + tapkey) & KEYM;
-                bq[t] = *reinterpret_cast<const bf16x8 *>(smem + p * CELLB + ((((kc << 2) | g) ^ key) << 4));
-            }
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(wk + wlane_off + i * 512);
         };
         auto multiply = [&](const bf16x8 (&a)[4], const bf16x8 (&bq)[T]) {
 #pragma unroll
@@ -173,31 +168,32 @@ __global__ void __launch_bounds__(256, 2) k_oth_conv(const uint16_t *x, const ui
             // their first use (left alone it does, and every k step waits out the L2 latency).
             // KPT is even, so the halves of the A buffer are back in place at the loop edge.
             bf16x8 a[2][4], bq[T];
+            int cb[T];                                   // cell0 moved to the current tap
+#pragma unroll
+            for (int t = 0; t < T; ++t) cb[t] = cell0[t];
             fetch_a(a[0], 0);
-            fetch_b(bq, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < T; ++t) bq[t] = *reinterpret_cast<const bf16x8 *>(smem + cb[t]);
 #pragma unroll 1
             for (int tap = 0; tap < 9; ++tap) {
-                const int tapcell = (tap / 3) * PW + (tap % 3);
-                const int ntap = tap < 8 ? tap + 1 : 8;
-                const int next_tapcell = (ntap / 3) * PW + (ntap % 3);
-                const int tapkey = (tap / 3) * HO + (tap % 3), next_tapkey = (ntap / 3) * HO + (ntap % 3);
+                const int ntap = tap < 8 ? tap + 1 : 8;                                     // the last step re-reads itself
+                const int to_next = (ntap / 3 - tap / 3) * ROWP + (ntap % 3 - tap % 3) * CELLP;   // wave-uniform
 #pragma unroll
                 for (int kc = 0; kc < KPT; ++kc) {
                     const int ks = tap * KPT + kc;
-                    fetch_a(a[(kc + 1) & 1], ks + 1 < KS ? ks + 1 : ks);                     // the last step re-reads itself
+                    fetch_a(a[(kc + 1) & 1], ks + 1 < KS ? ks + 1 : ks);
                     __builtin_amdgcn_sched_barrier(0);
-                    const int ncell = kc + 1 < KPT ? tapcell : next_tapcell;
-                    const int nkey = kc + 1 < KPT ? tapkey : next_tapkey;
-                    const int nkc = (kc + 1) % KPT;
 #pragma unroll
                     for (int t = 0; t < T; ++t) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
                             acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kc & 1][i], bq[t], acc[i][t], 0, 0, 0);
-                        int p = cell0[t] + ncell;
-                        asm volatile("" : "+v"(p));          // recompute the address here: hoisted, the 8 x T offsets of a tap cost 56 registers
-                        const int key = ((t == T - 1 ? tl_last : tl) + nkey) & KEYM;
-                        bq[t] = *reinterpret_cast<const bf16x8 *>(smem + p * CELLB + ((((nkc << 2) | g) ^ key) << 4));
+                        if (kc + 1 < KPT) {
+                            bq[t] = *reinterpret_cast<const bf16x8 *>(smem + cb[t] + (kc + 1) * 64);       // offset field
+                        } else {
+                            cb[t] += to_next;                                                              // one add per tap and tile
+                            bq[t] = *reinterpret_cast<const bf16x8 *>(smem + cb[t]);
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -207,7 +203,9 @@ __global__ void __launch_bounds__(256, 2) k_oth_conv(const uint16_t *x, const ui
 #pragma unroll 1
             for (int tap = 0; tap < 9; ++tap) {
                 fetch_a(a, tap);
-                fetch_b(bq, (tap / 3) * PW + (tap % 3), (tap / 3) * HO + (tap % 3), 0);
+                const int off = (tap / 3) * ROWP + (tap % 3) * CELLP;
+#pragma unroll
+                for (int t = 0; t < T; ++t) bq[t] = *reinterpret_cast<const bf16x8 *>(smem + cell0[t] + off);
                 multiply(a, bq);
             }
         }
@@ -279,7 +277,8 @@ int launch(const void *x, const void *wp, const float *pre_s, const float *pre_b
            const float *post_b, const void *res, void *y, int64_t B, const int64_t *batch_dev, hipStream_t s)
 {
     constexpr int PW = HI + 2 * PAD, HO = PW - 2;
-    constexpr int IMG = PW * PW * CIN * 2, STAGE = HO * HO * ROWB;
+    constexpr int CELLP = CIN * 2 + 16, ROWP = PW * CELLP + (256 - (2 * CELLP) % 256) % 256;   // the kernel's image layout
+    constexpr int IMG = PW * ROWP, STAGE = HO * HO * ROWB;
     constexpr int SMEM = IMG > STAGE ? IMG : STAGE;
     auto kern = k_oth_conv<CIN, HI, PAD, PRE, RES, SILU>;
     static bool attr_set = false;
