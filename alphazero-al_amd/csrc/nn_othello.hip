@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 
 #include "az_nn.h"
@@ -101,7 +102,7 @@ __global__ void __launch_bounds__(256, 2) k_oth_conv(const uint16_t *x, const ui
     const int wlane_off = (wave * 4) * 512 + lane * 8;           // this lane's place in a k step's 16 weight fragments
 
     for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
-        // ---- copy: sample -> zero-padded, swizzled image (the BatchNorm in front of the convolution rides here)
+        // ---- copy: sample -> zero-padded image (the BatchNorm in front of the convolution rides here)
         const uint16_t *xs = x + b * (HI * HI * CIN);
         // the pre-affine of the channel chunk this thread copies (loaded per sample: 16 registers that
         // must not stay live through the MFMA phase)
@@ -167,7 +168,9 @@ __global__ void __launch_bounds__(256, 2) k_oth_conv(const uint16_t *x, const ui
                 for (int i = 0; i < 4; ++i)
                     acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bq[t], acc[i][t], 0, 0, 0);
         };
-        if constexpr (KPT >= 2) {
+        if (dbg & 2) {
+            // timing experiment (AZ_OTH_DEBUG=2, results wrong): no MFMA phase - what the copy and output phases cost alone
+        } else if constexpr (KPT >= 2) {
             // Software pipeline over k steps.  Weight fragments (L2, ~1 us away) of step k+1 are
             // requested before the MFMAs of step k, into the other half of a register double
             // buffer; a token fragment (LDS) of step k+1 is requested as soon as the four MFMAs
@@ -294,9 +297,15 @@ int launch(const void *x, const void *wp, const float *pre_s, const float *pre_b
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
             return 2;
         attr_set = true;
+        if (getenv("AZ_NN_VERBOSE") != nullptr) {
+            int per_cu = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), 256, SMEM);
+            fprintf(stderr, "[az_nn] othello conv C_in=%d H=%d pad=%d: %d B LDS, %d workgroups per CU\n", CIN, HI, PAD, SMEM, per_cu);
+        }
     }
     static const int dbg = getenv("AZ_OTH_DEBUG") ? atoi(getenv("AZ_OTH_DEBUG")) : 0;
-    const unsigned grid = static_cast<unsigned>(B < 512 ? B : 512);      // two workgroups per CU, persistent over samples
+    static const int64_t max_grid = getenv("AZ_OTH_GRID") ? atoll(getenv("AZ_OTH_GRID")) : 512;   // two workgroups per CU, persistent over samples
+    const unsigned grid = static_cast<unsigned>(B < max_grid ? B : max_grid);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), SMEM, s, static_cast<const uint16_t *>(x),
                        static_cast<const uint16_t *>(wp), pre_s, pre_b, post_s, post_b,
                        static_cast<const uint16_t *>(res), static_cast<uint16_t *>(y), B, dbg, batch_dev);
