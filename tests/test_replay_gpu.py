@@ -346,6 +346,20 @@ def test_config5_network_table_verify_and_refresh(env):
 
 # ---------------------------------------------------------------------------- BASELINE configs 2 and 3/4 at their own sizes
 
+def test_config1_full_size_equals_oracle(env):
+    """BASELINE config 1 - the configuration `bench.py` times: Connect4, 8192 games, n_playout 200 (c_base 1000), K 4,
+    actor configuration (noise, symmetry) - three plies with a re-rooting between them through the native loop,
+    every tree bit-exact against the oracle (replayed draws, hash evaluator)."""
+    rng = np.random.default_rng(200)
+    b, t = S.random_openings(rng, 512, 18)
+    boards = np.tile(b, (16, 1, 1)); turns = np.tile(t, 16)
+    n, K = 200, 4
+    cfg = dict(S.ACTOR_CFG, c_base=5.0 * n)
+    tape = oracle_with_tape(S.C4Game, O.BatchedMCTS_Connect4, cfg, boards, turns, n, K, 3, seed=1)
+    counts, stats = device_loop_with_tape(env, "Connect4", cfg, boards, turns, n, K, 3, tape, True)
+    _compare(tape, counts, stats)
+
+
 def test_config2_full_size_equals_oracle(env):
     """BASELINE config 2's per-GPU share - Connect4, 8192 games, n_playout 800 (c_base 4000), K 4, actor
     configuration - one ply through the native loop, every tree bit-exact against the oracle (replayed
