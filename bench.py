@@ -90,7 +90,7 @@ def parse():
                          "evaluator kernels; 1 = one driver, one batch of games x vl_batch leaves per iteration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-games", type=int, default=256)
-    ap.add_argument("--cpu-plies", type=int, default=2)
+    ap.add_argument("--cpu-plies", type=int, default=6)
     return ap.parse_args()
 
 
