@@ -97,6 +97,21 @@ __device__ __forceinline__ void wave_add_counter(unsigned long long *counters, i
         atomicAdd(&counters[(blockIdx.x % CNT_STRIPES) * CNT_N + which], static_cast<unsigned long long>(v));
 }
 
+// sum over the wavefront on the DPP network (no LDS crossbar trips), the total in every lane's copy of lane 63
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v)
+{
+    auto mv = [](unsigned x, auto ctrl, auto rmask) {
+        return static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), decltype(ctrl)::value, decltype(rmask)::value, 0xf, false));
+    };
+    v += mv(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xf>{});     // quad_perm [1,0,3,2]
+    v += mv(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xf>{});     // quad_perm [2,3,0,1]
+    v += mv(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xf>{});    // row_half_mirror
+    v += mv(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xf>{});    // row_mirror
+    v += mv(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});    // row_bcast:15 into rows 1 and 3
+    v += mv(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});    // row_bcast:31 into rows 2 and 3
+    return static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
+}
+
 template <int L>
 __device__ __forceinline__ HotRec group_bcast(const HotRec &c, int src)
 {
@@ -797,9 +812,17 @@ __global__ void __launch_bounds__(WAVE) k_select8x4(TreeArena ar, RootState rs, 
         if (tree < ar.B && j == 0 && sub == 0 && add != 0) hot[root].n_inflight = rootrec.n_inflight + add;
     }
 
-    wave_add_counter(counters, CNT_LEVELS, sub == 0 ? n_levels : 0u);
-    wave_add_counter(counters, CNT_TERMINAL, sub == 0 ? n_terminal : 0u);
-    wave_add_counter(counters, CNT_SIMS, (live && sub == 0) ? 1u : 0u);
+    // the three work counters in one reduction: levels of a group < 2^12, one terminal flag and one simulation each
+    {
+        const unsigned packed = sub == 0 ? (n_levels | (n_terminal << 16) | ((live ? 1u : 0u) << 24)) : 0u;
+        const unsigned tot = wave_sum_u32(packed);
+        if (lane == 0) {
+            unsigned long long *c = counters + (blockIdx.x % CNT_STRIPES) * CNT_N;
+            if (tot & 0xffffu) atomicAdd(&c[CNT_LEVELS], static_cast<unsigned long long>(tot & 0xffffu));
+            if ((tot >> 16) & 0xffu) atomicAdd(&c[CNT_TERMINAL], static_cast<unsigned long long>((tot >> 16) & 0xffu));
+            if (tot >> 24) atomicAdd(&c[CNT_SIMS], static_cast<unsigned long long>(tot >> 24));
+        }
+    }
 }
 
 // ------------------------------------------------------------------ virtual-loss removal
@@ -1214,9 +1237,16 @@ __global__ void __launch_bounds__(WAVE) k_backprop_batched(TreeArena ar, LeafBuf
         }
         if (sub == 0 && used != used0) ar.used[t] = used;
     }
-    wave_add_counter(counters, CNT_EXPANSIONS, sub == 0 ? n_exp : 0u);
-    wave_add_counter(counters, CNT_DUP, sub == 0 ? n_dup : 0u);
-    wave_add_counter(counters, CNT_BACKUP, n_backup);
+    // the three work counters in one reduction: a wavefront backs up < 2^16 nodes, expands and skips <= 32 leaves
+    {
+        const unsigned tot = wave_sum_u32(n_backup | (sub == 0 ? (n_exp << 16) | (n_dup << 24) : 0u));
+        if (lane == 0) {
+            unsigned long long *c = counters + (blockIdx.x % CNT_STRIPES) * CNT_N;
+            if ((tot >> 16) & 0xffu) atomicAdd(&c[CNT_EXPANSIONS], static_cast<unsigned long long>((tot >> 16) & 0xffu));
+            if (tot >> 24) atomicAdd(&c[CNT_DUP], static_cast<unsigned long long>(tot >> 24));
+            if (tot & 0xffffu) atomicAdd(&c[CNT_BACKUP], static_cast<unsigned long long>(tot & 0xffffu));
+        }
+    }
 }
 
 // ------------------------------------------------------------------ leaf gather
