@@ -163,7 +163,10 @@ struct az_mcts {
     int64_t prune_seq = 0;
     int64_t ring_seq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t growth_after[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int64_t last_extra = 0;   // room asked for by the last search (one ply's worst-case growth)
+    int64_t last_extra = 0;   // room asked for by the last ensure_room call
+    int64_t growth_since_prune = 0;   // room handed out since the previous re-rooting = one ply's worst-case growth,
+                                      // whether it was asked for in one call (device loop) or in one call per
+                                      // backprop (host entry points)
     int64_t epoch = 0;        // bumped whenever a buffer the dev_* kernels address moves
 
     // roots of the current call
@@ -211,6 +214,7 @@ struct az_mcts {
     int profile_stride = 1;      // time every profile_stride-th launch of a kind
     int64_t profile_seen[2] = {0, 0};
     EventRing ev_select, ev_backprop;
+    const char *timed_select_kernel = "";   // the kernel behind the newest timed selection launch (az_mcts_timed_select_kernel)
 
     // IO buffers of the host entry points
     DevBuf<int8_t> io_boards_in, io_boards_out;
@@ -350,6 +354,7 @@ struct az_mcts {
         used_bound += extra;
         for (auto &g : growth_after) g += extra;
         last_extra = extra;
+        growth_since_prune += extra;
     }
 
     void check_device_error()
@@ -384,7 +389,11 @@ struct az_mcts {
         // compact the trees that could not take two more plies' worth of growth where they are
         // (AZ_COMPACT_ALWAYS=1: every tree at every re-rooting)
         static const bool always = getenv("AZ_COMPACT_ALWAYS") != nullptr && getenv("AZ_COMPACT_ALWAYS")[0] == '1';
-        const int64_t above = always ? 0 : std::max<int64_t>(S / 8, S - 2 * std::max<int64_t>(last_extra, geo.max_edges));
+        // (one ply = what was reserved since the previous re-rooting; the host entry points reserve per backprop
+        // call, so the last call's figure alone would let a tree run into the end of its half mid-search)
+        const int64_t ply = std::max<int64_t>(std::max(growth_since_prune, last_extra), geo.max_edges);
+        growth_since_prune = 0;
+        const int64_t above = always ? 0 : std::max<int64_t>(S / 8, S - 2 * ply);
         az::launch_prune(game, arena(), params(), actions_dev, noise_req, dev_noise, s, noise_replay, max_live.p, err.p,
                          static_cast<int>(above));
         HIP_OK(hipMemcpyAsync(const_cast<int *>(&live_ring[q % 8]), max_live.p, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -998,8 +1007,8 @@ void select_and_gather(az_mcts *m, int K, int vl, float *features, uint8_t *vali
     m->last_select_vl = vl != 0;
     const az::SearchParams p = m->params();
     const bool timed = m->profiling && (m->profile_seen[0]++ % m->profile_stride) == 0 && m->ev_select.begin(s);
-    az::launch_select(m->game, m->arena(), m->roots(), ls.view(), p, K, vl != 0, m->counters.p, s, m->call_ctr.p, zero_count);
-    if (timed) m->ev_select.end(s);
+    const char *kn = az::launch_select(m->game, m->arena(), m->roots(), ls.view(), p, K, vl != 0, m->counters.p, s, m->call_ctr.p, zero_count);
+    if (timed) { m->ev_select.end(s); m->timed_select_kernel = kn; }
     bool gen_sym = true;
     if (m->replay_sym != nullptr) {             // recorded symmetry ids instead of the generator's
         if (m->replay_next >= m->replay_calls || static_cast<int64_t>(total) > m->replay_stride)
@@ -1032,12 +1041,15 @@ void select_and_prep(az_mcts *m, int K, int vl, uint8_t *valid_mask, int32_t *ro
     m->last_select_vl = vl != 0;
     const az::SearchParams p = m->params();
     const bool timed = m->profiling && (m->profile_seen[0]++ % m->profile_stride) == 0 && m->ev_select.begin(s);
-    az::launch_select(m->game, m->arena(), m->roots(), ls.view(), p, K, vl != 0, m->counters.p, s, m->call_ctr.p, n_rows);
-    if (timed) m->ev_select.end(s);
+    const char *kn = az::launch_select(m->game, m->arena(), m->roots(), ls.view(), p, K, vl != 0, m->counters.p, s, m->call_ctr.p, n_rows);
+    if (timed) { m->ev_select.end(s); m->timed_select_kernel = kn; }
     bool gen_sym = true;
     if (m->replay_sym != nullptr) {             // recorded symmetry ids instead of the generator's
         if (m->replay_next >= m->replay_calls || static_cast<int64_t>(total) > m->replay_stride)
             throw AzError(AZ_ERR_STATE, "dev_select: the replay tape (az_mcts_dev_replay) is exhausted or too narrow");
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            throw AzError(AZ_ERR_STATE, "dev_select: a replay tape cannot be captured into a graph (its position moves per call)");
         HIP_OK(hipMemcpyAsync(ls.sym.p, m->replay_sym + m->replay_next * m->replay_stride, sizeof(int32_t) * total,
                               hipMemcpyDeviceToDevice, s));
         ++m->replay_next;
@@ -1292,6 +1304,16 @@ int az_mcts_dev_leaves(az_mcts *m, int K, uint64_t *bb_p1, uint64_t *bb_p2, int3
     });
 }
 
+int az_mcts_dev_leaf_syms(az_mcts *m, int K, int32_t *sym_ids, void *stream)
+{
+    return guarded([&] {
+        LeafStore &ls = m->last_select_vl ? m->vl_leaf : m->plain_leaf;
+        const size_t total = static_cast<size_t>(m->B) * K;
+        require(ls.slot.n >= total && sym_ids != nullptr, "dev_leaf_syms: no selection of that width");
+        HIP_OK(hipMemcpyAsync(sym_ids, ls.sym.p, 4 * total, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    });
+}
+
 int az_mcts_dev_counts(az_mcts *m, int32_t *counts, void *stream)
 {
     return guarded([&] { az::launch_counts(m->game, m->arena(), counts, static_cast<hipStream_t>(stream)); });
@@ -1416,6 +1438,8 @@ int az_mcts_profile(az_mcts *m, int enable)
         m->profile_seen[0] = m->profile_seen[1] = 0;
     });
 }
+
+const char *az_mcts_timed_select_kernel(az_mcts *m) { return m ? m->timed_select_kernel : ""; }
 
 int az_mcts_profile_read(az_mcts *m, double out_ms[2], int64_t out_launches[2])
 {

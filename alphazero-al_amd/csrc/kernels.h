@@ -108,9 +108,10 @@ void launch_set_roots(int game, const uint64_t *bb0, const uint64_t *bb1, const 
                       int B, hipStream_t s);
 void launch_bump_call(uint64_t *call_ctr, hipStream_t s);
 // bump_call: the device generator's call counter, incremented once by the launch (nullptr: not)
-void launch_select(int game, TreeArena ar, RootState rs, LeafBuf lf, SearchParams p, int K, bool vl,
-                   unsigned long long *counters, hipStream_t s, uint64_t *bump_call = nullptr,
-                   int64_t *zero = nullptr);   // zero: an int64 the launch clears (the live-leaf count)
+// returns the name of the kernel it launched (a string literal)
+const char *launch_select(int game, TreeArena ar, RootState rs, LeafBuf lf, SearchParams p, int K, bool vl,
+                          unsigned long long *counters, hipStream_t s, uint64_t *bump_call = nullptr,
+                          int64_t *zero = nullptr);   // zero: an int64 the launch clears (the live-leaf count)
 void launch_backprop(int game, TreeArena ar, LeafBuf lf, SearchParams p, int K, bool vl, bool fused,
                      EvalIn in, unsigned long long *counters, int *err, hipStream_t s);
 void launch_remove_vl(int game, TreeArena ar, LeafBuf lf, SearchParams p, int K, int strideK, hipStream_t s);

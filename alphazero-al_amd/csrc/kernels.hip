@@ -813,6 +813,9 @@ __global__ void __launch_bounds__(WAVE) k_select8x4(TreeArena ar, RootState rs, 
     }
 
     // the three work counters in one reduction: levels of a group < 2^12, one terminal flag and one simulation each
+    // (8 groups per wavefront: 8 x C4_MAX_PATH levels in 16 bits, <= 8 terminal leaves and simulations in 8 bits each;
+    // readlane(63) needs every lane of the wavefront here: no path of this kernel may return before this point)
+    static_assert(8 * C4_MAX_PATH < 65536, "the level counter of a wavefront is a 16-bit field");
     {
         const unsigned packed = sub == 0 ? (n_levels | (n_terminal << 16) | ((live ? 1u : 0u) << 24)) : 0u;
         const unsigned tot = wave_sum_u32(packed);
@@ -1237,7 +1240,11 @@ __global__ void __launch_bounds__(WAVE) k_backprop_batched(TreeArena ar, LeafBuf
         }
         if (sub == 0 && used != used0) ar.used[t] = used;
     }
-    // the three work counters in one reduction: a wavefront backs up < 2^16 nodes, expands and skips <= 32 leaves
+    // the three work counters in one reduction: a wavefront backs up < 2^16 nodes, expands and skips <= 32 leaves.
+    // The fields must not carry into each other, and readlane(63) needs every lane of the wavefront here:
+    // no path of this kernel may return before this point.
+    static_assert((WAVE / G::LANES) * KMAX < 256, "expansion / duplicate counters of a wavefront are 8-bit fields");
+    static_assert((WAVE / G::LANES) * KMAX * G::MAX_PATH < 65536, "the backup-node counter of a wavefront is a 16-bit field");
     {
         const unsigned tot = wave_sum_u32(n_backup | (sub == 0 ? (n_exp << 16) | (n_dup << 24) : 0u));
         if (lane == 0) {
@@ -1759,8 +1766,8 @@ void launch_bump_call(uint64_t *call_ctr, hipStream_t s)
     hipLaunchKernelGGL(k_bump_call, dim3(1), dim3(1), 0, s, call_ctr);
 }
 
-void launch_select(int game, TreeArena ar, RootState rs, LeafBuf lf, SearchParams p, int K, bool vl,
-                   unsigned long long *counters, hipStream_t s, uint64_t *bump_call, int64_t *zero)
+const char *launch_select(int game, TreeArena ar, RootState rs, LeafBuf lf, SearchParams p, int K, bool vl,
+                          unsigned long long *counters, hipStream_t s, uint64_t *bump_call, int64_t *zero)
 {
     // AZ_SELECT_VARIANT: 0 = k_select (the first kernel, every game), 1 = k_select8 (Connect4) for every launch,
     // 3 (default) = k_select8x4 for virtual-loss batches of 2..4 descents, k_select8 for the rest
@@ -1768,14 +1775,14 @@ void launch_select(int game, TreeArena ar, RootState rs, LeafBuf lf, SearchParam
     if (game == Connect4Dev::GAME_ID && variant >= 3 && vl && K >= 2 && K <= 4) {
         hipLaunchKernelGGL(k_select8x4, dim3(grid_for(ar.B, 2)), dim3(WAVE), 0, s, ar, rs, lf, p, K, counters, bump_call,
                            reinterpret_cast<long long *>(zero));
-        return;
+        return "k_select8x4";
     }
     if (game == Connect4Dev::GAME_ID && variant >= 1) {
         const int tpw = trees_per_wave(Connect4Dev::LANES);
         const dim3 grid(grid_for(ar.B, tpw)), block(WAVE);
         if (vl) hipLaunchKernelGGL((k_select8<true>), grid, block, 0, s, ar, rs, lf, p, K, tpw, counters, bump_call, reinterpret_cast<long long *>(zero));
         else    hipLaunchKernelGGL((k_select8<false>), grid, block, 0, s, ar, rs, lf, p, K, tpw, counters, bump_call, reinterpret_cast<long long *>(zero));
-        return;
+        return vl ? "k_select8<true>" : "k_select8<false>";
     }
     AZ_DISPATCH(game, {
         const int tpw = trees_per_wave(G::LANES);
@@ -1783,6 +1790,8 @@ void launch_select(int game, TreeArena ar, RootState rs, LeafBuf lf, SearchParam
         if (vl) hipLaunchKernelGGL((k_select<G, true>), grid, block, 0, s, ar, rs, lf, p, K, tpw, counters, bump_call, reinterpret_cast<long long *>(zero));
         else    hipLaunchKernelGGL((k_select<G, false>), grid, block, 0, s, ar, rs, lf, p, K, tpw, counters, bump_call, reinterpret_cast<long long *>(zero));
     });
+    if (game == Connect4Dev::GAME_ID) return vl ? "k_select<Connect4Dev,true>" : "k_select<Connect4Dev,false>";
+    return vl ? "k_select<OthelloDev,true>" : "k_select<OthelloDev,false>";
 }
 
 void launch_backprop(int game, TreeArena ar, LeafBuf lf, SearchParams p, int K, bool vl, bool fused,

@@ -46,6 +46,7 @@ def lib():
         L.az_mcts_dev_select.argtypes = [vp, i32, i32, vp, vp, vp]
         L.az_mcts_dev_backprop.argtypes = [vp, i32, i32, vp, vp, vp, vp]
         L.az_mcts_dev_leaves.argtypes = [vp, i32, vp, vp, vp, vp, vp]
+        L.az_mcts_dev_leaf_syms.argtypes = [vp, i32, vp, vp]
         L.az_mcts_dev_counts.argtypes = [vp, vp, vp]
         L.az_mcts_dev_root_stats.argtypes = [vp, vp, vp]
         L.az_mcts_dev_prune_roots.argtypes = [vp, vp, vp]

@@ -5,20 +5,29 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+With `--gpus N` (N > 1) and no launcher around it, bench.py starts the N ranks ITSELF: the parent - before
+it imports torch or touches a GPU - runs `python -m torch.distributed.run --nproc-per-node N bench.py ...` as
+a child process, relays rank 0's line and exits non-zero unless that line says `n_gpus: N`.  A rank whose
+WORLD_SIZE differs from `--gpus` refuses to run.
+
 A "step" is one ply played in every one of the 8192 games of a rank: 200 simulations per
 tree (1 warm-up + 50 virtual-loss iterations of 4), each iteration = HIP selection + leaf
-gather -> the reference's CNN (random init, bf16 autocast, PyTorch-ROCm) -> HIP
+preparation -> the reference's CNN (random init; its hand-written HIP inference twin, bf16 with f32
+accumulation as the reference's autocast: nn_*.hip, no PyTorch kernel) -> HIP
 expansion/backup, then action sampling, re-rooting with fresh Dirichlet noise and the game
 step, all resident in HBM (alphazero-al_amd/src/selfplay.py).  Ranks hold independent game
 shards (weak scaling); the only collective is one all-reduce of the counters at the end.
 
 Output: ONE JSON line on rank 0.  `value` = positions/s of the whole job.  `roofline` is for
-the dominant hand-written kernel (tree selection): algorithmic bytes per launch (SURVEY.md
+the tree path's selection kernel - the path `north_star` asks an HBM roofline for; it is NOT the kernel
+with the largest share of a step (the evaluator's kernels are: `roofline_evaluator_kernels` carries all of
+them against both roofs): algorithmic bytes per launch (SURVEY.md
 8(d): 28+29E per level with E=7, plus 16 B of leaf state per simulation, from the engine's
 own level/simulation counters) over the kernel's mean duration measured with HIP events on
 the launch stream during the timed region.  `cpu_baseline` times the reference's C++/OpenMP
 search (oracle/_ref, compiled from the reference's sources) with the same network on the
-host cores, on a bounded sample.
+host cores, on a bounded sample of the GPU leg's own positions; `tree_only` / `cpu_baseline_tree_only`
+repeat both legs with the integer-hash evaluator (no network on either side).
 """
 import argparse
 import json
@@ -61,10 +70,52 @@ def host_cores():
 PROFILE_EVERY = 16       # an event pair costs the stream ~5 us: six kinds of kernel are timed, so every 16th iteration carries them (0.3 % of a step)
 
 
-def select_kernel_name():
-    """The selection kernel a virtual-loss launch runs (kernels.hip launch_select, AZ_SELECT_VARIANT)."""
+def select_kernel_name(lib=None, handle=None):
+    """The selection kernel behind the timed launches: asked of the engine (az_mcts_timed_select_kernel reports what
+    launch_select actually launched); without an engine, what kernels.hip launch_select would pick for a
+    virtual-loss batch of 2..4 descents under AZ_SELECT_VARIANT."""
+    if lib is not None and handle is not None:
+        import ctypes as C
+        lib.az_mcts_timed_select_kernel.restype = C.c_char_p
+        lib.az_mcts_timed_select_kernel.argtypes = [C.c_void_p]
+        name = lib.az_mcts_timed_select_kernel(handle)
+        if name:
+            return name.decode()
     v = int(os.environ.get("AZ_SELECT_VARIANT", "3"))
     return {0: "k_select<Connect4Dev,true>", 1: "k_select8<true>", 2: "k_select8<true>"}.get(v, "k_select8x4")
+
+
+def self_launch(args):
+    """`--gpus N` with N > 1 and no launcher around this process: start the N ranks as a CHILD process
+    (`python -m torch.distributed.run`, one rank per GPU) - never exec, and before this process has imported
+    torch or touched a GPU - relay what the ranks print, and fail unless rank 0's line says n_gpus == N."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    log("--gpus %d without a launcher: starting %d ranks: %s" % (args.gpus, args.gpus, " ".join(cmd)))
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for out in child.stdout:
+        sys.stdout.write(out)
+        sys.stdout.flush()
+        if out.startswith("{"):
+            line = out
+    rc = child.wait()
+    if rc != 0:
+        raise SystemExit("bench.py: the %d-rank run exited with code %d" % (args.gpus, rc))
+    try:
+        seen = json.loads(line)["n_gpus"] if line else None
+    except Exception:
+        seen = None
+    if seen != args.gpus:
+        raise SystemExit("bench.py: asked for %d GPUs, the run reported n_gpus=%r" % (args.gpus, seen))
+    return 0
 
 
 def parse():
@@ -89,25 +140,41 @@ def parse():
                          "host thread (selfplay.StreamedSelfPlay): one group's tree kernels run under another group's "
                          "evaluator kernels; 1 = one driver, one batch of games x vl_batch leaves per iteration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tree-only", action="store_true", help="skip the tree-only pair (tree_only / cpu_baseline_tree_only)")
+    ap.add_argument("--tree-only-steps", type=int, default=40)
     ap.add_argument("--cpu-games", type=int, default=256)
     ap.add_argument("--cpu-plies", type=int, default=6)
     return ap.parse_args()
 
 
-def cpu_baseline(args, rank):
-    """Reference C++/OpenMP search (oracle/_ref) + the same CNN on the host CPU, through the
-    reference-compatible wrapper, on a bounded sample of the same workload."""
+def dump_positions(sp, n):
+    """The first `n` games of the GPU leg as they stand (bitboards in HBM -> host arrays): the CPU leg plays on from
+    the very positions the timed region ended on - games of all ages - instead of from empty boards."""
     import numpy as np
-    import torch
+    part = sp.parts[0]
+    n = min(int(n), part.B)
+    return (part.bb_p1[:n].cpu().numpy().astype(np.uint64), part.bb_p2[:n].cpu().numpy().astype(np.uint64),
+            part.turn[:n].cpu().numpy().astype(np.int32))
+
+
+def cpu_baseline(args, evaluator, positions):
+    """Reference C++/OpenMP search (oracle/_ref) + the same evaluator on the host CPU, through the
+    reference-compatible wrapper, on a bounded sample of the same workload: `positions` are games of the GPU leg
+    (dump_positions); a game that ends restarts from the empty board, as on the GPU."""
+    import tempfile
+    import numpy as np
     ref_dirs = [os.path.join(ROOT, "oracle", "_ref", v) for v in ("portable", "native")]
     ref_dir = next((d for d in ref_dirs if os.path.isdir(os.path.join(d, "src"))), None)
     if os.environ.get("AZ_BENCH_FORCE_PORT") == "1":
         ref_dir = None
     cores = host_cores()
+    games, plies = args.cpu_games, args.cpu_plies
+    if evaluator == "hash":            # tree-only leg: no network on the CPU either, so a sample of the default size lasts 40 ms
+        games, plies = max(games, 4096), max(plies, 8)
     if ref_dir is None:
         # oracle/_ref did not travel: the plain-C restatement (oracle/, single-threaded search) takes its place
-        kind, games = "port", min(args.cpu_games, 64)
-        log(f"cpu_baseline: oracle C restatement (1 thread) + CNN on {cores} host threads ...")
+        kind, games = "port", min(games, 64)
+        log(f"cpu_baseline[{evaluator}]: oracle C restatement (1 thread) + evaluator on {cores} host threads ...")
         head = f"""
 import sys, time, json, os
 import numpy as np, torch
@@ -117,10 +184,8 @@ from src import MCTS_cpp as W
 W._BACKENDS['Connect4'] = O.BatchedMCTS_Connect4
 """
     else:
-        kind, games = "reference", args.cpu_games
-        if args.evaluator == "hash":            # tree-only leg: no network on the CPU either, so a sample of the default size lasts 40 ms
-            games, args.cpu_plies = max(games, 4096), max(args.cpu_plies, 8)
-        log(f"cpu_baseline: reference C++/OpenMP search + CNN on {cores} host threads ...")
+        kind = "reference"
+        log(f"cpu_baseline[{evaluator}]: reference C++/OpenMP search + evaluator on {cores} host threads ...")
         head = f"""
 import sys, time, json, os
 import numpy as np, torch
@@ -130,32 +195,71 @@ import importlib.util
 spec = importlib.util.spec_from_file_location('az_wrap', os.path.join({PKG!r}, 'src', 'MCTS_cpp.py'))
 W = importlib.util.module_from_spec(spec); spec.loader.exec_module(W)
 """
+    tmp = None
+    if positions is not None:
+        bb1, bb2, turn = (np.asarray(a)[:games] for a in positions)
+        games = int(bb1.shape[0])
+        tmp = tempfile.NamedTemporaryFile(prefix="az_bench_positions_", suffix=".npz", delete=False)
+        np.savez(tmp, bb1=bb1, bb2=bb2, turn=turn)
+        tmp.close()
     code = head + f"""
 import importlib.util
 spec = importlib.util.spec_from_file_location('az_net', os.path.join({PKG!r}, 'src', 'az_net.py'))
 N = importlib.util.module_from_spec(spec); spec.loader.exec_module(N)
 torch.manual_seed(0); torch.set_num_threads({cores})
-if {args.evaluator!r} == 'hash':
+if {evaluator!r} == 'hash':
     spec = importlib.util.spec_from_file_location('az_hash', os.path.join({PKG!r}, 'src', 'hash_eval.py'))
     H = importlib.util.module_from_spec(spec); spec.loader.exec_module(H)
     net = H.NumpyHashEvaluator()                # tree-only leg: the integer-hash evaluator in numpy
 else:
     net = N.Connect4Net(device='cpu').eval()
-B, n, K, plies = {games}, {args.n_playout}, {args.vl_batch}, {args.cpu_plies}
+B, n, K, plies = {games}, {args.n_playout}, {args.vl_batch}, {plies}
 w = W.BatchedMCTS(B, c_init=1.4, c_base=5*n, alpha=0.3, n_playout=n, noise_epsilon=0.25,
                   fpu_reduction=0.2, use_symmetry=True, mlh_slope=0.1, mlh_cap=0.2)
 w.seed(0)
 boards = np.zeros((B, 6, 7), np.int8); turns = np.ones(B, np.int32)
+src = {(tmp.name if tmp else None)!r}
+if src:
+    z = np.load(src)
+    for c in range(7):                          # bit 7*col + height; row 0 is the top of the board (Connect4.h:15-29)
+        for h in range(6):
+            bit = np.uint64(7 * c + h)
+            boards[:, 5 - h, c] = ((z['bb1'] >> bit) & np.uint64(1)).astype(np.int8) - ((z['bb2'] >> bit) & np.uint64(1)).astype(np.int8)
+    turns = z['turn'].astype(np.int32)
+stones = int(np.abs(boards).sum())
+def ended(g, r, c):                             # four in a row through (r, c), or a full board (Connect4.h:159-203)
+    p = g[r, c]
+    for dr, dc in ((0, 1), (1, 0), (1, 1), (1, -1)):
+        run = 1
+        for sg in (1, -1):
+            rr, cc = r + sg * dr, c + sg * dc
+            while 0 <= rr < 6 and 0 <= cc < 7 and g[rr, cc] == p:
+                run += 1; rr += sg * dr; cc += sg * dc
+        if run >= 4:
+            return True
+    return not (g == 0).any()
+finished = 0
 t0 = time.perf_counter()
 for ply in range(plies):
     w.batch_playout(net, boards, turns, vl_batch=K, fused=False)
     c = w.get_visits_count(); a = c.argmax(1).astype(np.int32)
     w.prune_roots(a)
+    restart = []
     for i in range(B):
-        col = boards[i][:, a[i]]; r = np.where(col == 0)[0].max(); boards[i][r, a[i]] = turns[i]
-    turns = -turns
+        col = boards[i][:, a[i]]
+        free = np.where(col == 0)[0]
+        if free.size == 0:                      # cannot happen for a searched, unfinished position
+            restart.append(i); continue
+        r = free.max(); boards[i][r, a[i]] = turns[i]; turns[i] = -turns[i]
+        if ended(boards[i], r, a[i]):
+            restart.append(i)
+    if restart:                                 # finished games restart from the empty board, their trees reset
+        finished += len(restart)
+        boards[restart] = 0; turns[restart] = 1
+        for i in restart:
+            w.reset_env(int(i))
 dt = time.perf_counter() - t0
-print(json.dumps(dict(value=B*plies/dt, seconds=dt, positions=B*plies)))
+print(json.dumps(dict(value=B*plies/dt, seconds=dt, positions=B*plies, stones=stones, finished=finished)))
 """
     import subprocess
     env = dict(os.environ, OMP_NUM_THREADS=str(cores), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
@@ -164,16 +268,24 @@ print(json.dumps(dict(value=B*plies/dt, seconds=dt, positions=B*plies)))
         line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
         r = json.loads(line)
     except Exception as e:                      # the baseline is a reported extra, never fatal
-        sys.stderr.write(f"cpu_baseline failed: {e}\n")
+        sys.stderr.write(f"cpu_baseline failed: {e}\n" + (out.stderr[-2000:] if "out" in dir() else ""))
         return None
+    finally:
+        if tmp is not None:
+            try:
+                os.unlink(tmp.name)
+            except OSError:
+                pass
     what = (f"reference C++/OpenMP search (oracle/_ref/{os.path.basename(ref_dir)})" if kind == "reference"
             else "oracle/ C restatement of the reference search, one thread")
-    ev = (f"same CNN fp32 on CPU ({cores} torch threads)" if args.evaluator == "cnn"
+    ev = (f"same CNN fp32 on CPU ({cores} torch threads)" if evaluator == "cnn"
           else "integer-hash evaluator in numpy (tree-only leg)")
+    start = (f"continued from {games} of the GPU leg's own games as they stood after its timed region "
+             f"(all ages: {r['stones'] / max(games, 1):.1f} stones per board on average; {r['finished']} games ended and restarted)"
+             if positions is not None else f"{games} games from EMPTY boards")
     return {"value": round(r["value"], 2), "unit": "positions/s", "cores": cores, "kind": kind,
-            "sample": f"{games} games x {args.cpu_plies} plies from EMPTY boards (openings only: shallower trees and no "
-                      f"terminal leaves, a lighter mix than the GPU leg's games of all ages), n_playout={args.n_playout}, "
-                      f"vl_batch={args.vl_batch}, {what} + {ev}, {r['seconds']:.1f} s"}
+            "sample": f"{plies} plies, {start}, n_playout={args.n_playout}, vl_batch={args.vl_batch}, "
+                      f"{what} + {ev}, {r['seconds']:.1f} s"}
 
 
 def conv_roofline(torch, fast, leaves, launches=20):
@@ -211,12 +323,19 @@ def conv_roofline(torch, fast, leaves, launches=20):
 
 def main():
     args = parse()
-    import torch
-    import torch.distributed as dist
-
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args)                 # the parent never imports torch.cuda: its children own the GPUs
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d ranks were launched (rank %d): refusing to print a line "
+                         "for another job size" % (args.gpus, world, rank))
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the search engine has no CPU path)")
     # rehearsal of the multi-rank path on a one-GPU box: AZ_BENCH_REHEARSE=1 puts every rank on
@@ -224,6 +343,9 @@ def main():
     rehearse = os.environ.get("AZ_BENCH_REHEARSE", "0") == "1"
     if rehearse:
         local = 0
+    elif local >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d wants cuda:%d, this node shows %d GPUs (one rank per GPU; "
+                         "AZ_BENCH_REHEARSE=1 rehearses the multi-rank path on one GPU)" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -339,8 +461,9 @@ def main():
             # tools/collect_traffic.py): a stored measurement is only quoted for the configuration it was
             # taken on - kernel, trees per launch, n_playout, K, streams, evaluator - otherwise null
             traffic = None
+            sel_kernel = select_kernel_name(L, handles[0])
             traffic_key = "%s|games=%d|n_playout=%d|K=%d|streams=%d|evaluator=%s|lead_in=%d" % (
-                select_kernel_name(), args.games, args.n_playout, args.vl_batch, args.streams, args.evaluator, args.lead_in)
+                sel_kernel, args.games, args.n_playout, args.vl_batch, args.streams, args.evaluator, args.lead_in)
             tf = os.path.join(ROOT, "profiles", "traffic_select.json")
             if os.path.exists(tf):
                 try:
@@ -361,7 +484,12 @@ def main():
             del src, dst
             roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_key": traffic_key,
-                        "kernel": select_kernel_name(), "avg_launch_us": round(avg_ms * 1e3, 2),
+                        "traffic_source": "profiles/traffic_select.json: PMC passes (FETCH_SIZE x 2 + WRITE_SIZE) taken on exactly this "
+                                          "configuration by tools/collect_traffic.py; null for any other" if traffic is not None else None,
+                        "kernel": sel_kernel, "avg_launch_us": round(avg_ms * 1e3, 2),
+                        "bound_note": "priced against the HBM roof as north_star asks for the tree walk; the counters say the kernel is "
+                                      "limited by vector-instruction issue (DESIGN.md section 3), and it is a few percent of a step - the "
+                                      "kernels that dominate a step are in roofline_evaluator_kernels",
                         "avg_event_pair_us": round(raw_ms * 1e3, 2), "empty_event_pair_us": round(pair_ms * 1e3, 2),
                         "launches_timed": sel_n, "algorithmic_bytes_per_launch": int(per_launch_bytes),
                         "measured_copy_GBs": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 6),
@@ -453,7 +581,31 @@ def main():
             out["transposition_table"] = {"entries": 1 << args.table, "lookups": st["lookups"], "hits": st["hits"],
                                           "hit_rate": round(st["hit_rate"], 4), "replaced": st["replaced"]}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, rank)
+            out["cpu_baseline"] = cpu_baseline(args, args.evaluator, dump_positions(sp, args.cpu_games))
+            if args.evaluator == "cnn" and not args.no_tree_only:
+                # the same pair with the network factored out: tree kernels only (integer-hash evaluator, native on
+                # the GPU, numpy on the CPU) - GPU search against the reference's search, nothing else in the way
+                sp.close()
+                del sp, handles
+                torch.cuda.empty_cache()
+                from src.hash_eval import HashEvaluator
+                sp2 = StreamedSelfPlay(HashEvaluator(dev), args.games, streams=1, n_playout=args.n_playout,
+                                       vl_batch=args.vl_batch, seed=rank)
+                sp2.step(args.lead_in + 1)
+                torch.cuda.synchronize()
+                before = sp2.read_totals()["positions"]
+                F.check(L.az_mcts_counters_reset(sp2.parts[0].h))
+                t1 = time.perf_counter()
+                sp2.step(args.tree_only_steps)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+                c2 = sp2.engine_counters()
+                pos2 = sp2.read_totals()["positions"] - before
+                out["tree_only"] = {"value": round(pos2 / dt, 1), "unit": "positions/s", "steps": args.tree_only_steps,
+                                    "ms_per_step": round(dt / args.tree_only_steps * 1e3, 3),
+                                    "sims_per_s": round(c2["sims"] / dt, 1), "node_expansions_per_s": round(c2["expansions"] / dt, 1),
+                                    "evaluator": "integer-hash evaluator (native, no network): selection + leaf preparation + backup + game logic"}
+                out["cpu_baseline_tree_only"] = cpu_baseline(args, "hash", dump_positions(sp2, max(args.cpu_games, 4096)))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

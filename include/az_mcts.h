@@ -128,7 +128,10 @@ int az_mcts_get_all_root_stats(az_mcts *m, float *out);
 /* Must be called OUTSIDE any stream capture before the other dev_* calls and again whenever
  * the live config changed: sizes the leaf buffers for K descents per tree, refreshes the
  * c_puct table, and guarantees arena room for `sims_per_tree` more simulations per tree
- * (grows the arenas if needed; synchronises). */
+ * (grows the arenas if needed; synchronises).  Reserve PER SEARCH: the host-side occupancy bound restarts
+ * from the figure each az_mcts_dev_prune_roots reports, so room reserved before a re-rooting for
+ * searches enqueued after it is forgotten - call this once for every search, after the re-rooting that
+ * precedes it (as selfplay.py / fused.py do). */
 int az_mcts_dev_prepare(az_mcts *m, int K, int64_t sims_per_tree);
 /* The same for a caller whose work on these trees is all on ONE stream: when the call has to look
  * at the trees (their fill), move a buffer or refresh a table, it waits for that stream only
@@ -175,6 +178,10 @@ int az_mcts_dev_backprop(az_mcts *m, int K, int vl, const float *probs, const fl
  * 2 P2).  Any pointer may be NULL. */
 int az_mcts_dev_leaves(az_mcts *m, int K, uint64_t *bb_p1, uint64_t *bb_p2, int32_t *turns,
                        uint8_t *flags, void *stream);
+/* Symmetry ids the leaves of the last dev_select (or of the last selection inside az_mcts_dev_search) were shown
+ * under: int32[n*K] into HBM (0 for terminal leaves) - what BatchedMCTS.h:148-154,261-267 draws per leaf; lets a
+ * test look at the device generator's draws themselves (tests/test_devrng_gpu.py). */
+int az_mcts_dev_leaf_syms(az_mcts *m, int K, int32_t *sym_ids, void *stream);
 /* Root visit counts int32[n_envs*A] / root stats float32[n_envs*(6+8A)] into HBM. */
 int az_mcts_dev_counts(az_mcts *m, int32_t *counts, void *stream);
 int az_mcts_dev_root_stats(az_mcts *m, float *stats, void *stream);
@@ -293,6 +300,9 @@ int az_mcts_counters_reset(az_mcts *m);
 #define AZ_PROFILE_MAX 8192
 int az_mcts_profile(az_mcts *m, int enable);
 int az_mcts_profile_read(az_mcts *m, double out_ms[2], int64_t out_launches[2]);
+/* Name of the kernel behind the newest TIMED selection launch ("" before the first one): what the
+ * engine launched, not what an environment knob asked for (static string, never NULL). */
+const char *az_mcts_timed_select_kernel(az_mcts *m);
 
 /* Test hook for the host generator: `count` Dirichlet-gamma draws from one fresh
  * gamma(alpha,1) object on an mt19937 seeded with `seed` (checked against libstdc++). */

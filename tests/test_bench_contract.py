@@ -52,3 +52,42 @@ def test_timed_region_of_bench_does_not_touch_the_oracle():
     src = open(os.path.join(ROOT, "bench.py")).read()
     main = src[src.index("def main():"):]
     assert "oracle" not in main.replace("oracle/_ref", ""), "only the cpu_baseline leg may name the oracle"
+
+
+def test_gpus_flag_disagreeing_with_the_launched_ranks_fails_loudly():
+    """A rank whose WORLD_SIZE is not `--gpus` must not print a line for another job size (checked before torch is
+    imported, so no GPU is needed to see it)."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1"],
+                       capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not r.stdout.strip()
+
+
+def test_gpus_flag_starts_the_launcher_as_a_child(monkeypatch):
+    """`--gpus N` without WORLD_SIZE: the parent builds a `torch.distributed.run --nproc-per-node N` command for
+    itself, runs it as a CHILD (Popen, no exec), relays the line and insists on n_gpus == N."""
+    import subprocess
+    b = _bench()
+    seen = {}
+
+    class FakeChild:
+        def __init__(self, cmd, **kw):
+            seen["cmd"], seen["env"] = cmd, kw.get("env", {})
+            self.stdout = iter(['{"n_gpus": %d, "value": 1.0}\n' % seen.get("report", 4)])
+
+        def wait(self):
+            return 0
+
+    monkeypatch.setattr(subprocess, "Popen", FakeChild)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "5", "--warmup", "1"])
+    assert b.main() == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "5", "--warmup", "1"]
+    assert seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0" or os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") is not None
+    seen["report"] = 1                                # a run that reports another size is a failure
+    import pytest
+    with pytest.raises(SystemExit):
+        b.main()

@@ -74,6 +74,22 @@ def test_two_rank_rehearsal_reduces_the_counters():
     assert "cpu_baseline" not in j                                  # rank 0 at N = 1 only
 
 
+def test_gpus_flag_launches_the_ranks_itself():
+    """`python bench.py --gpus 2` with NO launcher on the command line: the parent starts torch.distributed.run as a
+    child process, both ranks play their shard (here on the one GPU of the box: AZ_BENCH_REHEARSE=1), and the
+    relayed line is the two-rank job's."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["AZ_BENCH_REHEARSE"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--evaluator", "hash"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _last_json(r.stdout)
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak"
+    positions = j["value"] * j["ms_per_step"] * 1e-3 * j["steps"]
+    assert abs(positions - 2 * 1024 * 3) < 2 * 1024 * 3 * 1e-3
+    assert "cpu_baseline" not in j
+
+
 def test_rccl_backend_reduces_the_counters_single_rank():
     """The collective of a multi-GPU run - one all-reduce SUM of six int64 counters and one MAX of a float64,
     on device tensors over RCCL (`backend="nccl"`) - executed for real on this box's GPU with a one-rank
