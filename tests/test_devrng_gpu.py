@@ -277,14 +277,14 @@ def test_connect4_consecutive_calls_and_symmetry_ids(env):
 
 
 def test_othello_noise_up_to_33_edges_and_symmetry_subset(env):
-    """Othello: roots with 1..~20 legal moves from random play (1024 distinct openings, each in 16 trees; every
-    edge count with >= 3000 rows is checked), the widest root the openings hold in 8192 trees of its own, and
+    """Othello: roots with 1..~20 legal moves from random play (1024 distinct openings, each in 40 trees; every
+    edge count with >= 1200 rows is checked), the widest root the openings hold in 8192 trees of its own, and
     symmetry ids uniform over the subset {0, 2, 6, 7} (Othello.h:363-367)."""
     import gc
     L = env["F"].lib()
     rng = np.random.default_rng(17)
-    n0, rep = 1024, 16
-    b0, t0 = S.ot_openings(rng, n0, 44)
+    n0, rep = 1024, 40
+    b0, t0 = S.ot_openings(rng, n0, 30)
     e0 = []
     for i in range(n0):
         mv = S.ot_moves(b0[i], int(t0[i]))
@@ -297,7 +297,7 @@ def test_othello_noise_up_to_33_edges_and_symmetry_subset(env):
         w, net = make_search(env, "Othello", B, alpha, seed=29, n_playout=5)
         w.batch_playout(net, boards, turns, vl_batch=4, fused=True)
         for E, (idx, x) in sorted(ot_edge_rows(w.get_root_stats(), edges).items()):
-            if x.shape[0] < 3000:
+            if x.shape[0] < 1200:
                 continue
             host = host_dirichlet(L, alpha, E, 40000, seed=500 + E)
             problems += ["Othello alpha=%.2f E=%d: %s" % (alpha, E, p) for p in dirichlet_problems(x, alpha, host)]

@@ -77,6 +77,31 @@ def test_vs_oracle_arena_growth(mcts_cpp):
     _side_by_side(mcts_cpp, dict(S.DET_CFG, c_base=4000.0), 12, 800, 4, 7, 4, seed=None, rng_seed=3)
 
 
+def test_host_path_compacts_instead_of_growing(mcts_cpp):
+    """Host entry points (search_batch_vl / backprop_batch_vl / prune_roots), ten plies of 300 simulations: a tree
+    appends ~1500 records per ply - more than its 4096-record half holds over a game - and the re-rooting
+    compacts it (threshold derived from the room reserved SINCE THE PREVIOUS RE-ROOTING; with the last call's
+    reservation alone no tree was ever copied on this path and the arenas doubled at the third ply).  The
+    arenas keep their initial size and every result equals the oracle's bit for bit."""
+    rng = np.random.default_rng(4)
+    boards, turns = S.random_openings(rng, 24, 2)
+    cfg = dict(S.ACTOR_CFG, c_base=1500.0)
+    m = mcts_cpp.BatchedMCTS_Connect4(24)
+    o = O.BatchedMCTS_Connect4(24)
+    res = []
+    for eng in (m, o):
+        S.apply_cfg(eng, cfg)
+        eng.set_seed(17)
+        res.append(S.play_plies(eng, boards, turns, 300, 4, 10, record_leaves=True))
+    hip, orc = res
+    assert np.array_equal(hip["counts"], orc["counts"]) and np.array_equal(hip["sym"], orc["sym"])
+    assert np.array_equal(hip["leaf_sig"], orc["leaf_sig"]) and np.array_equal(bits(hip["stats"]), bits(orc["stats"]))
+    lib = C.CDLL(os.path.join(PKG, "lib", "libaz_mcts.so"))
+    lib.az_mcts_capacity.argtypes = [C.c_void_p]
+    lib.az_mcts_capacity.restype = C.c_int64
+    assert lib.az_mcts_capacity(m.handle) == 4096, "the arenas grew: compaction did not keep the trees inside their halves"
+
+
 def test_full_size_invariants(mcts_cpp):
     """BASELINE config 1 size: 8192 trees, n_playout 200, vl_batch 4."""
     B, n, K = 8192, 200, 4
