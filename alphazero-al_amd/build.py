@@ -51,7 +51,7 @@ def build_engine(force=False):
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     out = os.path.join(LIB, "libaz_mcts.so")
-    names = ("kernels", "tt_kernels", "engine", "nn_kernels", "nn_conv", "nn_attn", "nn_heads", "nn_model", "nn_othello", "nn_othello_heads")
+    names = ("kernels", "tt_kernels", "engine", "nn_kernels", "nn_conv", "nn_conv2", "nn_attn", "nn_heads", "nn_model", "nn_othello", "nn_othello_heads")
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     headers = _headers()
     jobs = []

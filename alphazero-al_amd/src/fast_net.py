@@ -44,6 +44,7 @@ def glue():
             L.az_nn_attn_post.argtypes = [vp, vp, vp, i64, vp]
             L.az_nn_heads_prep.argtypes = [vp, vp, vp, f32, vp, vp, i64, f32, vp]
             L.az_nn_conv_block.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, i64, f32, vp, vp]
+            L.az_nn_conv_block2.argtypes = [vp, vp, vp, vp, vp, i64, f32, vp, vp]
             L.az_nn_attn_block.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, f32, vp, vp]
             L.az_nn_heads.argtypes = [vp, C.POINTER(HeadsWeights), vp, vp, vp, vp, i64, f32, vp, vp, vp]
             L.az_nn_stem_embed.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp]
@@ -57,6 +58,27 @@ def glue():
         except OSError:
             _GLUE = False
     return _GLUE or None
+
+
+def fold_block(w, bias, gamma, beta):
+    """What az_nn_conv_block2 (include/az_nn.h) takes instead of (weight, bias, gamma, beta) of a residual block
+    y = x + silu(conv(GroupNorm1(x) * gamma + beta) + bias): the weight with gamma folded in and rounded to bf16 once
+    (OHWI), t1 (9, 64) = per border class the sum of those ROUNDED weights over the taps inside the board,
+    t2_scaled (9, 64) = log2(e) * (bias + the same sum of weight * beta).  Border class = 3 * rowclass + colclass,
+    0 = first row / column (the tap at -1 falls off the board), 1 = inner, 2 = last."""
+    w32 = w.float().contiguous()                                    # (O, I, 3, 3), the bf16 values the first kernel multiplies
+    wf = (w32 * gamma.float().view(1, -1, 1, 1)).to(torch.bfloat16)
+    wff = wf.float()
+    wb = w32 * beta.float().view(1, -1, 1, 1)
+    t1 = torch.zeros((9, w.shape[0]), dtype=torch.float32, device=w.device)
+    t2 = torch.zeros_like(t1)
+    taps = {0: (1, 2), 1: (0, 1, 2), 2: (0, 1)}
+    for rc in range(3):
+        for cc in range(3):
+            kh, kw = list(taps[rc]), list(taps[cc])
+            t1[3 * rc + cc] = wff[:, :, kh][:, :, :, kw].sum((1, 2, 3))
+            t2[3 * rc + cc] = bias.float() + wb[:, :, kh][:, :, :, kw].sum((1, 2, 3))
+    return (wf.contiguous(memory_format=torch.channels_last), t1.contiguous(), (t2 * 1.4426950408889634).contiguous())
 
 
 class HeadsWeights(C.Structure):

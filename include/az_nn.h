@@ -47,6 +47,17 @@ int az_nn_silu_add(const void *x, const void *bias, int channels, const void *re
 int az_nn_conv_block(const void *x, int c_in, const void *weight_ohwi, const void *bias, const void *gamma,
                      const void *beta, int residual, void *y, int64_t batch, float eps, const int64_t *batch_dev,
                      void *stream);
+/* The residual block (c_in 64, normalised, residual) in its second form (nn_conv2.hip): one wavefront per SIMD on
+ * 32x32x16 MFMAs, GroupNorm folded into weights and epilogue.  The caller prepares, once per set of weights
+ * (alphazero-al_amd/src/fast_net.py `fold_block`):
+ *   weight_folded_ohwi  bf16 (64, 3, 3, 64): weight * gamma[c_in], rounded to bf16 once
+ *   t1  float32 (9, 64): for border class k = 3 * rowclass + colclass (0 first / 1 inner / 2 last row or column)
+ *       the sum of the FOLDED (rounded) weights over the taps that fall inside the board and over c_in
+ *   t2_scaled  float32 (9, 64): log2(e) * (bias + the same sum of weight * beta)
+ * so that  conv(W, pad(GN(x)))[o, cell] + bias = rstd * (conv(Wf, pad(x)) - mean * t1[class(cell)][o]) + t2[class][o].
+ * Same result as az_nn_conv_block up to where the one bf16 rounding sits (weights instead of normalised activations). */
+int az_nn_conv_block2(const void *x, const void *weight_folded_ohwi, const float *t1, const float *t2_scaled, void *y,
+                      int64_t batch, float eps, const int64_t *batch_dev, void *stream);
 /* The stem with the embedding fused in: az_nn_embed + az_nn_conv_block(c_in 32) as one kernel
  * that builds its tokens from the feature planes (no (batch, 42, 32) tensor in HBM). */
 int az_nn_stem_embed(const float *features, const void *emb_own, const void *emb_opp, const void *pos,

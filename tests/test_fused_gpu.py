@@ -273,6 +273,57 @@ def test_mfma_conv_block_matches_torch(env):
             assert err.max().item() < 6e-2 and err.mean().item() < 4e-3, (B, cin, err.max().item(), err.mean().item())
 
 
+def test_mfma_conv_block2_matches_torch(env):
+    """nn_conv2.hip (the residual block on 32x32x16 MFMAs with GroupNorm folded into weights and epilogue) against the
+    same block in torch, fp32 maths on the same bf16 inputs - same bounds as the first kernel's test - and against the
+    first kernel itself (they differ by where one bf16 rounding sits)."""
+    torch = env["torch"]
+    import ctypes as C
+    import torch.nn.functional as TF
+    from src.fast_net import fold_block, glue
+    L = glue()
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device="cuda"); g.manual_seed(2)
+    bf = torch.bfloat16
+    for B in (1, 3, 8, 37, 1024, 1027, 6150):    # one sample, partial tiles, ragged tails, several tiles per workgroup
+        cin = 64
+        x = (torch.randn(B, 42, cin, device="cuda", generator=g) * 1.5 + 0.3).to(bf)
+        w = (torch.randn(64, cin, 3, 3, device="cuda", generator=g) / (3.0 * cin ** 0.5)).to(bf)
+        bias = torch.randn(64, device="cuda", generator=g).to(bf)
+        ga = (1 + 0.2 * torch.randn(cin, device="cuda", generator=g)).to(bf)
+        be = (0.2 * torch.randn(cin, device="cuda", generator=g)).to(bf)
+        wf, t1, t2s = fold_block(w, bias, ga, be)
+        y = torch.full((B + 2, 42, 64), float("nan"), device="cuda").to(bf)       # two guard samples behind the batch
+        assert L.az_nn_conv_block2(x.data_ptr(), wf.data_ptr(), t1.data_ptr(), t2s.data_ptr(), y.data_ptr(), B, 1e-5, None, s) == 0
+        y1 = torch.empty((B, 42, 64), device="cuda", dtype=bf)
+        w_ohwi = w.contiguous(memory_format=torch.channels_last)
+        assert L.az_nn_conv_block(x.data_ptr(), cin, w_ohwi.data_ptr(), bias.data_ptr(), ga.data_ptr(), be.data_ptr(), 1,
+                                  y1.data_ptr(), B, 1e-5, None, s) == 0
+        img = x.float().view(B, 6, 7, cin).permute(0, 3, 1, 2)
+        h = TF.group_norm(img, 1, ga.float(), be.float(), 1e-5)
+        ref = (TF.silu(TF.conv2d(h, w.float(), bias.float(), padding=1)) + img).permute(0, 2, 3, 1).reshape(B, 42, 64)
+        torch.cuda.synchronize()
+        assert torch.isnan(y[B:].float()).all(), "wrote behind the batch"
+        out = y[:B].float()
+        assert torch.isfinite(out).all(), B
+        # yardstick: the first kernel against the same pure-fp32 reference (most of either error is the bf16 rounding of
+        # the output itself: values of magnitude ~1.5 carry ~3e-3 of it on average)
+        err, err1 = (out - ref).abs(), (y1.float() - ref).abs()
+        assert err.max().item() < 6e-2 and err.mean().item() < 1.1 * err1.mean().item() + 2e-4, \
+            (B, err.max().item(), err.mean().item(), err1.max().item(), err1.mean().item())
+        d = (out - y1.float()).abs()
+        assert d.max().item() < 8e-2 and d.mean().item() < 5e-3, (B, d.max().item(), d.mean().item())
+        print("conv2 B=%d: max %.4f mean %.5f (first kernel: %.4f / %.5f)" % (B, err.max().item(), err.mean().item(),
+                                                                          err1.max().item(), err1.mean().item()))
+    # a compact batch whose size only the device knows
+    n_dev = torch.tensor([700], dtype=torch.int64, device="cuda")
+    y = torch.full((1027, 42, 64), float("nan"), device="cuda").to(bf)
+    assert L.az_nn_conv_block2(x[:1027].data_ptr(), wf.data_ptr(), t1.data_ptr(), t2s.data_ptr(), y.data_ptr(), 1027, 1e-5,
+                               n_dev.data_ptr(), s) == 0
+    torch.cuda.synchronize()
+    assert torch.isnan(y[700:].float()).all() and torch.equal(y[:700].view(torch.int16), out[:700].to(bf).view(torch.int16))
+
+
 def test_stem_with_fused_embedding_equals_two_kernels(env):
     """az_nn_stem_embed against az_nn_embed followed by the stem az_nn_conv_block: same arithmetic,
     bit-identical output; also through a gather list (compact batch)."""
