@@ -325,9 +325,11 @@ __global__ void __launch_bounds__(256, 1) k_conv2(const uint16_t *x, const uint1
         sv[0] = sv[1] = sv[2] = zu;
         pt1[0] = pt1[1] = pt2[0] = pt2[1] = zf;
     }
-    constexpr int PREP_STEPS = 1 + 6 + 48 + 14 + 6 + 6 + 12 + 3;
-    // (`stores_c`: the six row stores of the previous tile were issued AFTER the staging transfers and may stay in
-    // flight - the counter retires in issue order, and waiting for a store means waiting for HBM)
+    // (the sum of squares is NOT taken with v_dot2c_f32_bf16: its products carry bf16-like precision - measured: the mean
+    // error of the block against fp32 doubled, from 2.2e-3 to 4.7e-3; the plain sum, a product with 1.0, is exact there)
+    constexpr int DOTS = 12;                            // steps per 16-byte chunk: per dword one dot2 (sum) and two fma (squares)
+    constexpr int PREP_STEPS = 1 + 3 + (6 * DOTS + 3) + 14 + 6 + 18 + 3;
+    constexpr int ST_RED = 4 + 6 * DOTS + 3, ST_FIN = ST_RED + 14, ST_TAB = ST_FIN + 6;
     auto prep_step = [&](auto par_c, auto st_c, auto stores_c) {
         constexpr int PAR = decltype(par_c)::value, ST = decltype(st_c)::value;
         if constexpr (ST == 0) {
@@ -336,19 +338,26 @@ __global__ void __launch_bounds__(256, 1) k_conv2(const uint16_t *x, const uint1
             st_sum = 0.0f; st_sq = 0.0f;
         } else if constexpr (ST < 4) {                                       // the sample's 336 chunks: three reads in flight
             sv[ST - 1] = *reinterpret_cast<const u32x4 *>(&smem[sa[ST - 1] + PAR * IMG]);
-        } else if constexpr (ST < 4 + 6 * 9 - 3) {
-            // rounds j = 0..5 of 8 dot products; behind rounds 0-2 the register is refilled with chunk j + 3
-            constexpr int R = ST - 4, J = R < 27 ? R / 9 : 3 + (R - 27) / 8, W = R < 27 ? R % 9 : (R - 27) % 8;
-            if constexpr (W == 8) {
+        } else if constexpr (ST < ST_RED) {
+            // rounds j = 0..5 of DOTS steps; behind rounds 0-2 the register is refilled with chunk j + 3
+            constexpr int R = ST - 4, J = R < 3 * (DOTS + 1) ? R / (DOTS + 1) : 3 + (R - 3 * (DOTS + 1)) / DOTS;
+            constexpr int W = R < 3 * (DOTS + 1) ? R % (DOTS + 1) : (R - 3 * (DOTS + 1)) % DOTS;
+            if constexpr (W == DOTS) {
                 sv[J] = *reinterpret_cast<const u32x4 *>(&smem[sa[J + 3] + PAR * IMG]);
             } else {
                 if constexpr (W == 0) pin(sv[J % 3]);                       // one 16-byte read, not four narrowed ones at their uses
-                const bf16x2 v = __builtin_bit_cast(bf16x2, sv[J % 3][W >> 1]);
-                if constexpr (W & 1) { st_sq = __builtin_amdgcn_fdot2_f32_bf16(v, v, st_sq, false); pin(st_sq); }
-                else { st_sum = __builtin_amdgcn_fdot2_f32_bf16(v, __builtin_bit_cast(bf16x2, 0x3f803f80u), st_sum, false); pin(st_sum); }
+                const uint32_t wd = sv[J % 3][W / 3];
+                if constexpr (W % 3 == 0) {
+                    st_sum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, wd), __builtin_bit_cast(bf16x2, 0x3f803f80u), st_sum, false);
+                    pin(st_sum);
+                } else {
+                    const float f = (W % 3 == 1) ? __uint_as_float(wd << 16) : __uint_as_float(wd & 0xffff0000u);
+                    st_sq = __builtin_fmaf(f, f, st_sq);
+                    pin(st_sq);
+                }
             }
-        } else if constexpr (ST < 69) {
-            constexpr int W = ST - 55, Q = W % 7;
+        } else if constexpr (ST < ST_FIN) {
+            constexpr int W = ST - ST_RED, Q = W % 7;
             float &v = W < 7 ? st_sum : st_sq;
             if constexpr (Q == 0) v += dpp_mov<0xB1>(v);
             else if constexpr (Q == 1) v += dpp_mov<0x4E>(v);
@@ -358,8 +367,8 @@ __global__ void __launch_bounds__(256, 1) k_conv2(const uint16_t *x, const uint1
             else if constexpr (Q == 5) v += dpp_mov<0x143, 0xc>(v);
             else v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
             pin(v);
-        } else if constexpr (ST < 75) {
-            constexpr int W = ST - 69;
+        } else if constexpr (ST < ST_TAB) {
+            constexpr int W = ST - ST_FIN;
             if constexpr (W == 0) st_sum *= (1.0f / (CELLS * CIN));                                   // mean
             else if constexpr (W == 1) st_sq = __builtin_fmaf(st_sq, 1.0f / (CELLS * CIN), -st_sum * st_sum);
             else if constexpr (W == 2) st_sq = __builtin_amdgcn_rsqf(fmaxf(st_sq, 0.0f) + eps);       // rstd
@@ -369,7 +378,7 @@ __global__ void __launch_bounds__(256, 1) k_conv2(const uint16_t *x, const uint1
         } else {
             // the sample's table: 144 float4 per table, three rounds (registers of round k: k & 1); in the third, lanes
             // >= 16 redo the item they did in the second (same result, no predicate)
-            constexpr int W = ST - 75;
+            constexpr int W = ST - ST_TAB;
             auto item = [&](int k) { return k < 2 || lane < 16 ? lane + 64 * k : lane + 64 * (k - 1); };     // float4 number
             auto off = [&](int k) { return static_cast<uint32_t>(item(k)) * 16u; };
             auto uoff = [&](int k) { return static_cast<uint32_t>((item(k) >> 4) * UROW + (item(k) & 15) * 16); };
@@ -401,7 +410,7 @@ __global__ void __launch_bounds__(256, 1) k_conv2(const uint16_t *x, const uint1
             else if constexpr (W == 17) wr(K2{});
         }
     };
-    static_assert(PREP_STEPS >= 75 + 18, "step numbering of the preparation");
+    static_assert(PREP_STEPS >= ST_TAB + 18, "step numbering of the preparation");
     // the 36 MFMAs of token tile TT on the image of parity PAR; fill(slot) is issued behind MFMA number `slot`
     auto mfma_tile = [&](auto par_c, auto tt_c, f32x16 &acc, auto &&fill) {
         constexpr int PAR = decltype(par_c)::value, TT = decltype(tt_c)::value;
@@ -488,14 +497,14 @@ __global__ void __launch_bounds__(256, 1) k_conv2(const uint16_t *x, const uint1
         mfma_tile(par_c, T2{}, acc2, [&](auto s_c) {
             constexpr int S = decltype(s_c)::value;
             epi_fill(par_c, T1{}, acc1, s_c);
-            // the next tile's statistics and table: three steps per slot from slot 2 on
-            static_for<0, 3>([&](auto j_c) {
-                constexpr int ST = 3 * (S - 2) + decltype(j_c)::value;
+            // the next tile's statistics and table: four steps per slot from slot 2 on
+            static_for<0, 4>([&](auto j_c) {
+                constexpr int ST = 4 * (S - 2) + decltype(j_c)::value;
                 if constexpr (S >= 2 && ST < PREP_STEPS && !(DBG & 2))
                     prep_step(Q{}, std::integral_constant<int, ST>{}, std::integral_constant<bool, !FIRST && !(DBG & 2)>{});
             });
         });
-        static_assert(3 * (KSTEPS - 2) >= PREP_STEPS, "the preparation fits behind the MFMAs of one token tile");
+        static_assert(4 * (KSTEPS - 2) >= PREP_STEPS, "the preparation fits behind the MFMAs of one token tile");
         epi_load(par_c, T2{});        // before barrier A: the next staging overwrites this image
     };
 

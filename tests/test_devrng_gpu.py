@@ -101,9 +101,19 @@ def dirichlet_problems(x, alpha, host=None, sigmas=4.0):
             se = np.sqrt(x[:, comp].var() / n + h[:, comp].var() / h.shape[0])
             if dm > sigmas * se + 1e-7:
                 bad.append("mean of component %d: %.5f vs host %.5f" % (comp, x[:, comp].mean(), h[:, comp].mean()))
-        p = stats.ks_2samp(s, h.sum(1)).pvalue
-        if p < 1e-4:
-            bad.append("row sums differ from the host generator's (KS p = %.2e)" % p)
+        # row sums: rounding noise around one is not a property of the generator - compared are the rows that fall short
+        # of one by more than 1e-4 (the 1e-8 of the normalisation against tiny draws): their share, and at small alpha,
+        # where they are many, their distribution
+        hs = h.sum(1)
+        short, hshort = s < 1.0 - 1e-4, hs < 1.0 - 1e-4
+        fa, fb = short.mean(), hshort.mean()
+        se = np.sqrt(fa * (1 - fa) / n + fb * (1 - fb) / h.shape[0])
+        if abs(fa - fb) > sigmas * se + 1e-4:
+            bad.append("share of rows short of one: %.5f vs host %.5f" % (fa, fb))
+        if short.sum() > 500 and hshort.sum() > 500:
+            p = stats.ks_2samp(s[short], hs[hshort]).pvalue
+            if p < 1e-4:
+                bad.append("sums of the short rows differ from the host generator's (KS p = %.2e)" % p)
     return bad
 
 

@@ -19,6 +19,21 @@ bf, dev = torch.bfloat16, "cuda"
 x = (torch.randn(B, 42, 64, device=dev) * 1.2 + 0.3).to(bf)
 if os.environ.get("PROBE_ZERO") == "1":          # clock check: on zeros the chip holds its full clock (DVFS give-back)
     x.zero_()
+if os.environ.get("PROBE_REAL") == "1":          # activations of the random-init network on random positions (what the bench sees)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import numpy as np
+    import scenarios as S
+    from src.az_net import Connect4Net
+    from src.fast_net import FastConnect4Net
+    torch.manual_seed(1234)
+    net = FastConnect4Net.from_module(Connect4Net(device=dev).eval())
+    bd, tn = S.random_openings(np.random.default_rng(0), 512, 24)
+    planes = np.stack([(bd == tn[:, None, None]), (bd == -tn[:, None, None]), np.ones_like(bd) * tn[:, None, None]], 1).astype(np.float32)
+    feat = torch.from_numpy(np.tile(planes, (B // 512 + 1, 1, 1, 1))[:B]).to(dev).contiguous()
+    L.az_nn_stem_embed.argtypes = [C.c_void_p] * 7 + [C.c_int64] + [C.c_void_p] * 3
+    L.az_nn_stem_embed(feat.data_ptr(), net.emb_own.data_ptr(), net.emb_opp.data_ptr(), net.pos.data_ptr(), net.stem_w.data_ptr(),
+                       net.stem_b.data_ptr(), x.data_ptr(), B, None, None, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
 y = torch.empty_like(x)
 w = (torch.randn(64, 64, 3, 3, device=dev) * 0.05).to(bf)
 if os.environ.get("PROBE_ZERO") == "1":
@@ -27,6 +42,10 @@ w_ohwi = w.contiguous(memory_format=torch.channels_last)
 b = torch.randn(64, device=dev).to(bf)
 g = (1 + 0.1 * torch.randn(64, device=dev)).to(bf)
 be = (0.1 * torch.randn(64, device=dev)).to(bf)
+if os.environ.get("PROBE_REAL") == "1":
+    w = getattr(net, net.res[0][0]).clone(); b = getattr(net, net.res[0][1]).clone()
+    g = getattr(net, net.res[0][2]).clone(); be = getattr(net, net.res[0][3]).clone()
+    w_ohwi = w.contiguous(memory_format=torch.channels_last)
 wf, t1, t2s = fold_block(w, b, g, be)
 s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -63,10 +82,10 @@ else:
         a, c = timed(v1), timed(v2)
         print("round %d: %d leaves  v1 %6.1f us (%4.1f %% of 2.5 PF)   v2 %6.1f us (%4.1f %%)   dbg=%s" %
               (r, B, a, flops / (a * 1e-6) / 2.5e15 * 100, c, flops / (c * 1e-6) / 2.5e15 * 100, os.environ.get("AZ_NN_CONV2_DBG", "0")), flush=True)
-    st = np.zeros(256 * 4 * 4, dtype=np.uint64)
+    st = np.zeros(256 * 8 * 4, dtype=np.uint64)
     L.az_nn_conv2_stamps.argtypes = [C.c_void_p, C.c_int]
     L.az_nn_conv2_stamps(st.ctypes.data, st.size)
-    st = st.reshape(1024, 4).astype(np.float64)
+    st = st.reshape(2048, 4).astype(np.float64)
     st = st[st[:, 2] > 0]
     cyc, ticks, tiles = st[:, 0], st[:, 1], st[:, 2]
     print("   tile loop of the last v2 launch: %.0f cycles per tile (%.1f per MFMA), in-kernel clock %.2f GHz, loop %.1f us, %d-%d tiles per workgroup" %
