@@ -1103,7 +1103,10 @@ int az_mcts_dev_live_leaves(az_mcts *m, int K, int32_t *leaf_idx, int64_t *leaf_
 // expands every root, then ceil((n_playout-1)/K) virtual-loss batches) with the evaluator in the
 // loop, issued from native code: per iteration selection + gather, the list of leaves to evaluate,
 // the six evaluator launches, backup.  Nothing here waits for the device once the buffers exist.
-int az_mcts_dev_search(az_mcts *m, const az_nn_model *model, int n_playout, int K, int use_table, void *stream)
+namespace {
+// warmup: the schedule of a whole search (one plain simulation first, MCTS_cpp.py:217-248); without it the call
+// CONTINUES a search: n_playout more simulations in virtual-loss batches of K (plain ones for K <= 1)
+int dev_search_impl(az_mcts *m, const az_nn_model *model, int n_playout, int K, int use_table, bool warmup, void *stream)
 {
     return guarded([&] {
         require(model != nullptr, "dev_search: no evaluator model");
@@ -1170,13 +1173,24 @@ int az_mcts_dev_search(az_mcts *m, const az_nn_model *model, int n_playout, int 
             for (; remaining > 0; --remaining) iteration(1, 0);
             return;
         }
-        if (remaining > 0) { iteration(1, 0); --remaining; }
+        if (warmup && remaining > 0) { iteration(1, 0); --remaining; }
         while (remaining > 0) {
             const int k = std::min(K, remaining);
             remaining -= k;
             iteration(k, 1);
         }
     });
+}
+}  // namespace
+
+int az_mcts_dev_search(az_mcts *m, const az_nn_model *model, int n_playout, int K, int use_table, void *stream)
+{
+    return dev_search_impl(m, model, n_playout, K, use_table, true, stream);
+}
+
+int az_mcts_dev_search_more(az_mcts *m, const az_nn_model *model, int n_sims, int K, int use_table, void *stream)
+{
+    return dev_search_impl(m, model, n_sims, K, use_table, false, stream);
 }
 
 // ---- device transposition table ------------------------------------------------------------

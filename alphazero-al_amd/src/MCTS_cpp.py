@@ -274,9 +274,13 @@ class BatchedMCTS:
         if hasattr(pv_func, 'score_scale'):          # MCTS_cpp.py:106-108
             pv_func.score_scale = self.mcts.config.score_scale
 
-        runner = None if use_time else self._fused_runner(pv_func, fused)
+        runner = self._fused_runner(pv_func, fused)
         if runner is not None:
-            runner.playout(current_boards, turns, max_n, vl_batch)
+            if use_time:       # wall-clock check and top-2 early exit between chunks of whole iterations (fused.py search_timed)
+                self.last_playouts = runner.playout_timed(current_boards, turns, max_n, vl_batch, time_budget)
+            else:
+                runner.playout(current_boards, turns, max_n, vl_batch)
+                self.last_playouts = max_n
             return self
 
         t0 = time.perf_counter() if use_time else 0.0

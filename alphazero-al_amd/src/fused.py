@@ -64,6 +64,7 @@ def lib():
         L.az_game_dev_valid_mask.argtypes = [i32, vp, vp, vp, vp, vp, i64, vp]
         L.az_mcts_dev_live_leaves.argtypes = [vp, i32, vp, vp, vp]
         L.az_mcts_dev_search.argtypes = [vp, vp, i32, i32, i32, vp]
+        L.az_mcts_dev_search_more.argtypes = [vp, vp, i32, i32, i32, vp]
         L.az_mcts_dev_tt_create.argtypes = [vp, i32]
         L.az_mcts_dev_tt_clear.argtypes = [vp, vp]
         L.az_mcts_dev_tt_lookup.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
@@ -423,6 +424,77 @@ class FusedSearch:
             k = min(K, remaining)
             remaining -= k
             self._run(k, 1)
+
+    def search_timed(self, max_n, vl_batch, time_budget, early_exit=True, chunk_fraction=0.1):
+        """The reference's search under a TIME budget (MCTS_cpp.py:194-209 plain, 252-264 virtual loss) on the device
+        loop: before every chunk of whole iterations the wall clock is read and, from 8 simulations on, the top-2 test
+        of `_should_early_exit` (MCTS_cpp.py:70-87) is made on the root visit counts - which costs ONE drain of the
+        stream per chunk (the counts travel to pinned host memory behind the chunk's kernels).  A chunk is sized to
+        ~`chunk_fraction` of the budget from the measured time per simulation, so the search overshoots the budget by
+        at most about that share; `max_n` bounds the simulations as n_playout does.  Returns the simulations run.
+        Every chunk is whole iterations (selection + backup): no in-flight visits are left behind."""
+        import time
+        K = max(1, int(vl_batch))
+        t0 = time.perf_counter()
+        self._sync_fast_net()
+        model = self._native_model()
+        L, s = lib(), _stream()
+        if getattr(self, "_counts_dev", None) is None:
+            self._counts_dev = torch.zeros((self.B, self.A), dtype=torch.int32, device=self.device)
+            self._counts_host = torch.zeros((self.B, self.A), dtype=torch.int32).pin_memory()
+        table = 1 if self.table_log2 else 0
+
+        def run(n, first):
+            if model is not None:
+                fn = L.az_mcts_dev_search if first else L.az_mcts_dev_search_more
+                check(fn(self.h, model, int(n), K, table, s))
+                return
+            check(L.az_mcts_dev_prepare_stream(self.h, K, int(n), s))
+            left = n
+            if K <= 1 or first:
+                self._run(1, 0)
+                left -= 1
+            while left > 0:
+                k = min(K, left) if K > 1 else 1
+                left -= k
+                self._run(k, 1 if K > 1 else 0)
+
+        def counts():
+            check(L.az_mcts_dev_counts(self.h, self._counts_dev.data_ptr(), s))
+            self._counts_host.copy_(self._counts_dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            ev.synchronize()                                  # the one drain of this chunk
+            return self._counts_host.numpy()
+
+        total, remaining = 0, int(max_n)
+        if remaining > 0:
+            run(1, True)                                      # the warm-up simulation (plain path: the first one)
+            total, remaining = 1, remaining - 1
+        while remaining > 0:
+            c = counts()
+            elapsed = time.perf_counter() - t0
+            if elapsed >= time_budget:
+                break
+            per_sim = elapsed / total
+            if early_exit and total >= 8:
+                top2 = np.partition(c, -2, axis=1)[:, -2:]
+                if bool(np.all(top2.max(axis=1) - top2.min(axis=1) > (time_budget - elapsed) / per_sim)):
+                    break
+            # whole iterations worth about a tenth of the budget, never past the budget's end by more than one chunk
+            want = min(chunk_fraction * time_budget, time_budget - elapsed) / per_sim
+            n = int(min(remaining, max(K, (int(want) // K) * K)))
+            run(n, False)
+            total += n
+            remaining -= n
+        return total
+
+    def playout_timed(self, boards, turns, max_n, vl_batch, time_budget):
+        with torch.cuda.device(self.device):
+            self.upload_roots(boards, turns)
+            done = self.search_timed(max_n, vl_batch, time_budget)
+            torch.cuda.current_stream().synchronize()           # host entry points use the NULL stream
+        return done
 
     def playout(self, boards, turns, n_playout, vl_batch):
         with torch.cuda.device(self.device):

@@ -238,6 +238,13 @@ int az_mcts_dev_live_leaves(az_mcts *m, int K, int32_t *leaf_idx, int64_t *leaf_
 struct az_nn_model;
 int az_mcts_dev_search(az_mcts *m, const struct az_nn_model *model, int n_playout, int K, int use_table,
                        void *stream);
+/* CONTINUES a search on the same roots: n_sims more simulations per tree as whole iterations (virtual-loss batches of
+ * min(K, remaining); plain simulations for K <= 1) WITHOUT the warm-up simulation az_mcts_dev_search starts with.  A
+ * search under a time budget (MCTS_cpp.py:70-87,200-209,252-261: wall-clock check and top-2 early exit between
+ * iterations) is az_mcts_dev_search(.., 1, ..) followed by chunks of this call, with az_mcts_dev_counts read once per
+ * chunk - alphazero-al_amd/src/fused.py `search_timed`.  Every call leaves the trees without in-flight visits. */
+int az_mcts_dev_search_more(az_mcts *m, const struct az_nn_model *model, int n_sims, int K, int use_table,
+                            void *stream);
 
 /* ---- device transposition table of evaluator outputs (both games) ------------------------
  * Replaces, for the device loop, the LRU table of the reference's wrapper (src/Cache.py:5-58 used

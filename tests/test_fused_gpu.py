@@ -574,6 +574,50 @@ def test_native_search_call_equals_python_loop(env, monkeypatch):
         assert k0 == k1
 
 
+@pytest.mark.parametrize("native", ["1", "0"])
+def test_time_budgeted_search_stays_on_the_device(env, monkeypatch, native):
+    """`batch_playout(..., time_budget=...)` (MCTS_cpp.py:70-87,194-209,252-264 of the reference: wall-clock check and
+    top-2 early exit between iterations) on the fused path, native loop and Python loop: with a generous budget the
+    search runs its n_playout simulations and equals the n_playout-bounded search bit for bit (same launches, so the
+    same device draws); with a small one it stops early, on a whole iteration, with no in-flight visit left."""
+    monkeypatch.setenv("AZ_FUSED_NATIVE", native)
+    monkeypatch.setenv("AZ_FUSED_GRAPH", "0")
+    rng = np.random.default_rng(31)
+    boards, turns = S.random_openings(rng, 700, 10)
+    net = env["H"].HashEvaluator("cuda")
+
+    def make():
+        w = env["W"].BatchedMCTS(700, 1.4, 1000, 0.3, 200, noise_epsilon=0.25, fpu_reduction=0.2, use_symmetry=True)
+        w.seed(8)
+        return w
+    for K in (4, 1):
+        a, b = make(), make()
+        a.batch_playout(net, boards, turns, vl_batch=K, fused=True)
+        b.batch_playout(net, boards, turns, vl_batch=K, fused=True, time_budget=600.0)
+        assert b.last_playouts == 200 and b._fused is not None
+        assert np.array_equal(a.get_visits_count(), b.get_visits_count())
+        assert np.array_equal(bits(np.array(a.mcts.get_all_root_stats())), bits(np.array(b.mcts.get_all_root_stats())))
+    # a budget that ends the search long before n_playout = 10^6 simulations
+    c = env["W"].BatchedMCTS(700, 1.4, 1000, 0.3, 1000000, noise_epsilon=0.25, fpu_reduction=0.2, use_symmetry=True)
+    c.seed(8)
+    import time
+    t0 = time.perf_counter()
+    c.batch_playout(net, boards, turns, vl_batch=4, fused=True, time_budget=0.25)
+    dt = time.perf_counter() - t0
+    done = c.last_playouts
+    assert 1 <= done < 1000000 and (done - 1) % 4 == 0, done            # the warm-up simulation + whole batches of four
+    assert dt < 0.25 * 1.6 + 0.3, dt                                   # at most about one chunk (a tenth of the budget) late
+    st = np.array(c.mcts.get_all_root_stats())
+    live = np.array([not S.np_done(b) for b in boards])
+    assert (st[live, 0] == done).all() and (c.get_visits_count()[live].sum(1) == done - 1).all()
+    c.mcts.remove_all_vl(4)                                             # nothing in flight: removing virtual losses changes nothing
+    assert np.array_equal(bits(st), bits(np.array(c.mcts.get_all_root_stats())))
+    # budget already over after the warm-up simulation
+    d = make()
+    d.batch_playout(net, boards, turns, vl_batch=4, fused=True, time_budget=1e-9)
+    assert d.last_playouts == 1 and (np.array(d.mcts.get_all_root_stats())[live, 0] == 1).all()
+
+
 def test_device_generator_noise_and_symmetry(env):
     torch = env["torch"]
     rng = np.random.default_rng(9)
