@@ -155,8 +155,18 @@ def test_fast_inference_twin_g7(env):
              argmax=(p.argmax(1) == g["ckpt_probs"].argmax(1)).mean())
     print("twin vs G7:", {k: round(float(v), 5) for k, v in e.items()})
     assert e["p_max"] < 3e-2 and e["w_max"] < 5e-2, e
-    assert e["p_mean"] < 1.25 * e["ref_p_mean"] + 1e-4 and e["w_mean"] < 1.25 * e["ref_w_mean"] + 1e-4, e
+    assert e["p_mean"] < 1.1 * e["ref_p_mean"] + 1e-4 and e["w_mean"] < 1.1 * e["ref_w_mean"] + 1e-4, e
     assert e["argmax"] >= 0.99, e
+    # The whole error DISTRIBUTION of the twin sits at or below the module's own bf16 error: median, 90th and 99th
+    # percentile within 1.1x (measured: 1.2e-4 / 2.5e-3 / 8.0e-3 against the module's 1.3e-4 / 2.9e-3 / 8.2e-3 on the
+    # policy, 5.6e-4 / 3.4e-3 / 9.1e-3 against 5.4e-4 / 3.8e-3 / 1.05e-2 on WDL).  The maxima above are single values
+    # out of 1792 and 768 - one position each - and move by tens of percent with ANY change of evaluation order: the
+    # same architecture on plain PyTorch bf16 operations lands on 2.3e-2 / 4.0e-2 (tools/probe_twin_error.py, which also
+    # shows that the heads add 3e-3 / 7e-3 and the body - bf16 activations between layers, as in the module - the rest).
+    for q in (0.5, 0.9, 0.99):
+        for mine, ref, want, tag in ((p, pm, g["ckpt_probs"], "policy"), (w, wm, g["ckpt_wdl"], "wdl")):
+            a, b = np.quantile(np.abs(mine - want), q), np.quantile(np.abs(ref - want), q)
+            assert a <= 1.1 * b + 1e-4, (tag, q, a, b)
     # weight updates on the source module are picked up by the fused path
     w_ = env["W"].BatchedMCTS(8, 1.4, 100, 0.0, 9, noise_epsilon=0.0, use_symmetry=False)
     b, t = S.random_openings(np.random.default_rng(1), 8, 4)
