@@ -493,8 +493,8 @@ __global__ void __launch_bounds__(WAVE) k_select8(TreeArena ar, RootState rs, Le
         constexpr uint64_t TOP = 0x0000810204081020ull;               // the top cell of every column
         const int nv = term ? 0 : 7 - static_cast<int>(__builtin_popcountll((st.bb0 | st.bb1) & TOP));
         int32_t *path = lf.path + flat * G::MAX_PATH;
-        path[sub] = path0;                                             // entries past depth are ignored downstream
-        path[sub + 8] = path1;
+        if (sub <= depth) path[sub] = path0;                           // entries past depth are ignored downstream: not written
+        if (sub + 8 <= depth) path[sub + 8] = path1;                   // (they were 2 MB of stores per launch that nobody reads)
         if (sub == 0) {
             lf.slot[flat] = cur; lf.bb0[flat] = st.bb0; lf.bb1[flat] = st.bb1; lf.turn[flat] = st.turn;
             lf.flags[flat] = fl; lf.path_len[flat] = depth + 1; lf.aux[flat] = st.aux;
@@ -681,8 +681,8 @@ __global__ void __launch_bounds__(WAVE) k_select8x4(TreeArena ar, RootState rs, 
         constexpr uint64_t TOP = 0x0000810204081020ull;               // the top cell of every column
         const int nv = term ? 0 : 7 - static_cast<int>(__builtin_popcountll((st.bb0 | st.bb1) & TOP));
         int32_t *path = lf.path + flat * G::MAX_PATH;
-        path[sub] = path0;                                             // entries past depth are ignored downstream
-        path[sub + 8] = path1;
+        if (sub <= depth) path[sub] = path0;                           // entries past depth are ignored downstream: not written
+        if (sub + 8 <= depth) path[sub + 8] = path1;                   // (they were 2 MB of stores per launch that nobody reads)
         if (sub == 0) {
             lf.slot[flat] = cur; lf.bb0[flat] = st.bb0; lf.bb1[flat] = st.bb1; lf.turn[flat] = st.turn;
             lf.flags[flat] = fl; lf.path_len[flat] = depth + 1; lf.aux[flat] = st.aux;

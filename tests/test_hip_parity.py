@@ -77,12 +77,14 @@ def test_vs_oracle_arena_growth(mcts_cpp):
     _side_by_side(mcts_cpp, dict(S.DET_CFG, c_base=4000.0), 12, 800, 4, 7, 4, seed=None, rng_seed=3)
 
 
-def test_host_path_compacts_instead_of_growing(mcts_cpp):
-    """Host entry points (search_batch_vl / backprop_batch_vl / prune_roots), ten plies of 300 simulations: a tree
-    appends ~1500 records per ply - more than its 4096-record half holds over a game - and the re-rooting
-    compacts it (threshold derived from the room reserved SINCE THE PREVIOUS RE-ROOTING; with the last call's
-    reservation alone no tree was ever copied on this path and the arenas doubled at the third ply).  The
-    arenas keep their initial size and every result equals the oracle's bit for bit."""
+def test_host_path_compacts_at_re_rooting(mcts_cpp):
+    """Host entry points (search_batch_vl / backprop_batch_vl / prune_roots), ten plies of 300 simulations with the
+    most visited move played: a tree creates ~1600 records per ply, ~16 000 over the game - the reference's pools
+    would hold them all (MCTSNode.h:165-181: nothing is reclaimed before a reset) - and keeps most of its statistics
+    from ply to ply.  The re-rooting compacts the trees (threshold derived from the room reserved SINCE THE PREVIOUS
+    RE-ROOTING; with the last call's reservation alone no tree was ever copied on this path and the arenas doubled
+    three times): the arenas end at 8192 records per half, less than what was created, and every result equals the
+    oracle's bit for bit."""
     rng = np.random.default_rng(4)
     boards, turns = S.random_openings(rng, 24, 2)
     cfg = dict(S.ACTOR_CFG, c_base=1500.0)
@@ -99,7 +101,12 @@ def test_host_path_compacts_instead_of_growing(mcts_cpp):
     lib = C.CDLL(os.path.join(PKG, "lib", "libaz_mcts.so"))
     lib.az_mcts_capacity.argtypes = [C.c_void_p]
     lib.az_mcts_capacity.restype = C.c_int64
-    assert lib.az_mcts_capacity(m.handle) == 4096, "the arenas grew: compaction did not keep the trees inside their halves"
+    lib.az_mcts_counters.argtypes = [C.c_void_p, C.POINTER(C.c_int64 * 8)]
+    cnt = (C.c_int64 * 8)()
+    assert lib.az_mcts_counters(m.handle, C.byref(cnt)) == 0
+    created_per_tree = cnt[2] / 24 * 4            # expansions x at least four legal moves each (the boards are never that full here)
+    cap = lib.az_mcts_capacity(m.handle)
+    assert cap <= 8192 and created_per_tree > 1.2 * cap, (cap, created_per_tree)
 
 
 def test_full_size_invariants(mcts_cpp):
