@@ -127,6 +127,65 @@ __device__ __forceinline__ HotRec group_bcast(const HotRec &c, int src)
     return r;
 }
 
+// ---- one tree per wavefront (Othello: 64 lanes, up to 33 edges): the group-wide exchanges without the LDS crossbar.
+// A __shfl with a runtime lane is a ds_bpermute (address VGPR, LDS round trip, wait); in a loop bounded by the edge
+// count that is one dependent round trip per edge.  With the whole wavefront as the group the source lane is
+// wave-uniform, so v_readlane_b32 (a scalar result, no LDS) does it, and reductions run on the DPP network.
+
+// sum of `term` over lanes 0..E-1 IN LANE ORDER (the reference adds in edge order: MCTS.h:145-151,343-345); lanes
+// >= E must hold +0 (adding it changes nothing), so the common case is a fixed unrolled chain of 40 readlanes
+__device__ __forceinline__ float wave_ordered_sum(float term, int E)
+{
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 40; ++i) s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(term), i));
+    for (int i = 40; i < E; ++i) s += __shfl(term, i, WAVE);               // positions with more than 40 legal moves (imported roots)
+    return s;
+}
+// maximum of an unsigned key over the wavefront (0 = the identity of lanes switched off)
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
+{
+    auto mv = [](unsigned x, auto ctrl, auto rmask) {
+        return static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), decltype(ctrl)::value, decltype(rmask)::value, 0xf, false));
+    };
+    auto mx = [](unsigned a, unsigned b) { return a > b ? a : b; };
+    v = mx(v, mv(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xf>{}));     // quad_perm [1,0,3,2]
+    v = mx(v, mv(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xf>{}));     // quad_perm [2,3,0,1]
+    v = mx(v, mv(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xf>{}));    // row_half_mirror
+    v = mx(v, mv(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xf>{}));    // row_mirror
+    v = mx(v, mv(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{}));    // row_bcast:15 into rows 1 and 3
+    v = mx(v, mv(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{}));    // row_bcast:31 into rows 2 and 3
+    return static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
+}
+// strict '>' over ascending edges == highest score, lowest lane on ties; NaN and -inf never win (MCTS.h:172,226-231):
+// an order-preserving integer key of the score (0 for lanes that cannot win), its wave-wide maximum, the lowest lane
+// that holds it.  Returns -1 when no lane can win.
+__device__ __forceinline__ int wave_argmax(float score, bool can_win)
+{
+    const uint32_t b = __float_as_uint(score);
+    uint32_t key = (b & 0x80000000u) ? ~b : (b | 0x80000000u);             // monotone in the float order; -inf -> 0x007fffff
+    if (!can_win || !(score > -INFINITY)) key = 0u;                         // NaN fails the comparison too
+    const unsigned mx = wave_max_u32(key);
+    if (mx == 0u) return -1;
+    const unsigned long long hit = __ballot(key == mx);
+    return static_cast<int>(__builtin_ctzll(hit));
+}
+template <>
+__device__ __forceinline__ HotRec group_bcast<WAVE>(const HotRec &c, int src)
+{
+    const int u = __builtin_amdgcn_readfirstlane(src);                      // the winner's lane is the same in every lane
+    HotRec r;
+    r.n_visits   = __builtin_amdgcn_readlane(c.n_visits, u);
+    r.n_inflight = __builtin_amdgcn_readlane(c.n_inflight, u);
+    r.w_p1       = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.w_p1), u));
+    r.w_p2       = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.w_p2), u));
+    r.m_sum      = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.m_sum), u));
+    r.prior      = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.prior), u));
+    r.child_off  = __builtin_amdgcn_readlane(c.child_off, u);
+    r.meta       = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(c.meta), u));
+    return r;
+}
+
 // first record of tree t's arena: the half it lives in now (tree_layout.h: two halves per tree, a
 // re-rooting copies the kept subtree into the other one)
 __device__ __forceinline__ size_t tree_base(const TreeArena &ar, int t)
@@ -235,6 +294,8 @@ __global__ void __launch_bounds__(WAVE) k_select(TreeArena ar, RootState rs, Lea
                 if (L <= 8) {
 #pragma unroll
                     for (int i = 0; i < L - 1; ++i) seen += __shfl(seen_term, i, L);   // lanes >= E hold 0
+                } else if (L == WAVE) {
+                    seen = wave_ordered_sum(seen_term, E);
                 } else {
                     for (int i = 0; i < E; ++i) seen += __shfl(seen_term, i, L);
                 }
@@ -273,22 +334,28 @@ __global__ void __launch_bounds__(WAVE) k_select(TreeArena ar, RootState rs, Lea
 
                 // strict '>' over ascending edges == max score, lowest index on ties; NaN and
                 // -inf can never win (MCTS.h:172,226-231)
-                float s = (has && score == score) ? score : -INFINITY;
-                int si = sub;
+                if (L == WAVE) {
+                    best = wave_argmax(score, has);
+                } else {
+                    float s = (has && score == score) ? score : -INFINITY;
+                    int si = sub;
 #pragma unroll
-                for (int o = L / 2; o > 0; o >>= 1) {
-                    const float os = __shfl_xor(s, o, L);
-                    const int oi = __shfl_xor(si, o, L);
-                    if (os > s || (os == s && oi < si)) { s = os; si = oi; }
+                    for (int o = L / 2; o > 0; o >>= 1) {
+                        const float os = __shfl_xor(s, o, L);
+                        const int oi = __shfl_xor(si, o, L);
+                        if (os > s || (os == s && oi < si)) { s = os; si = oi; }
+                    }
+                    best = (s > -INFINITY) ? si : -1;
                 }
-                best = (s > -INFINITY) ? si : -1;
                 if (best < 0) stop = true;
             }
 
             if (!stop) {
                 ++n_levels;
                 if (VL && depth == 0) root_infl += p.vl_count;      // MCTS.h:470-475
-                const int action = __shfl(static_cast<int>(c.meta & META_ACTION_MASK), best, L);
+                const int action = L == WAVE
+                    ? __builtin_amdgcn_readlane(static_cast<int>(c.meta & META_ACTION_MASK), __builtin_amdgcn_readfirstlane(best))
+                    : __shfl(static_cast<int>(c.meta & META_ACTION_MASK), best, L);
                 G::step(st, action);
                 const int res = G::result(st);
                 const int child_slot = R.child_off + best;
@@ -939,7 +1006,7 @@ __global__ void __launch_bounds__(WAVE) k_backprop(TreeArena ar, LeafBuf lf, Sea
 #pragma unroll
                         for (int i = 0; i < L - 1; ++i) psum += __shfl(my_pol, i, L);
                     } else {
-                        for (int i = 0; i < nv; ++i) psum += __shfl(my_pol, i, L);
+                        if (L == WAVE) psum = wave_ordered_sum(my_pol, nv); else for (int i = 0; i < nv; ++i) psum += __shfl(my_pol, i, L);
                     }
                     const float prior = my_pol / (psum + 1e-8f);    // MCTS.h:370
                     if (static_cast<int64_t>(used) + nv > ar.S) {
@@ -957,7 +1024,7 @@ __global__ void __launch_bounds__(WAVE) k_backprop(TreeArena ar, LeafBuf lf, Sea
                         }
                         if (root_leaf && p.alpha > 0.0f && !in.root_noise) {
                             float sum = 0.0f;
-                            for (int i = 0; i < nv; ++i) sum += __shfl(noise, i, L);
+                            if (L == WAVE) sum = wave_ordered_sum(noise, nv); else for (int i = 0; i < nv; ++i) sum += __shfl(noise, i, L);
                             noise = noise * (1.0f / (sum + 1e-8f));
                         }
                         if (sub < nv) {
@@ -1149,7 +1216,7 @@ __global__ void __launch_bounds__(WAVE) k_backprop_batched(TreeArena ar, LeafBuf
 #pragma unroll
                         for (int i = 0; i < L - 1; ++i) psum += __shfl(my_pol[k], i, L);
                     } else {
-                        for (int i = 0; i < nv[k]; ++i) psum += __shfl(my_pol[k], i, L);
+                        if (L == WAVE) psum = wave_ordered_sum(my_pol[k], nv[k]); else for (int i = 0; i < nv[k]; ++i) psum += __shfl(my_pol[k], i, L);
                     }
                     const float prior = my_pol[k] / (psum + 1e-8f);  // MCTS.h:370
                     if (static_cast<int64_t>(used) + nv[k] > ar.S) {
@@ -1167,7 +1234,7 @@ __global__ void __launch_bounds__(WAVE) k_backprop_batched(TreeArena ar, LeafBuf
                         }
                         if (root_leaf && p.alpha > 0.0f && !in.root_noise) {
                             float sum = 0.0f;
-                            for (int i = 0; i < nv[k]; ++i) sum += __shfl(noise, i, L);
+                            if (L == WAVE) sum = wave_ordered_sum(noise, nv[k]); else for (int i = 0; i < nv[k]; ++i) sum += __shfl(noise, i, L);
                             noise = noise * (1.0f / (sum + 1e-8f));
                         }
                         if (sub < nv[k]) {
@@ -1464,8 +1531,7 @@ __global__ void __launch_bounds__(WAVE) k_prune(TreeArena ar, SearchParams p, co
                 DevRng rng(p.seed, *p.call_ptr, static_cast<uint64_t>(t), static_cast<uint64_t>(lane) + 128);
                 g = rng.gamma(p.alpha);
             }
-            float sum = 0.0f;
-            for (int i = 0; i < want0; ++i) sum += __shfl(g, i, WAVE);
+            const float sum = wave_ordered_sum(g, want0);   // lanes >= want0 hold 0
             if (lane < want0) cold[noff0 + lane].noise = g * (1.0f / (sum + 1e-8f));
         }
         return;
@@ -1531,8 +1597,7 @@ __global__ void __launch_bounds__(WAVE) k_prune(TreeArena ar, SearchParams p, co
             DevRng rng(p.seed, *p.call_ptr, static_cast<uint64_t>(t), static_cast<uint64_t>(lane) + 128);
             g = rng.gamma(p.alpha);
         }
-        float sum = 0.0f;
-        for (int i = 0; i < want; ++i) sum += __shfl(g, i, WAVE);
+        const float sum = wave_ordered_sum(g, want);   // lanes >= want hold 0
         if (lane < want) ncold[noff + lane].noise = g * (1.0f / (sum + 1e-8f));
     }
 }
