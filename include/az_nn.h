@@ -58,6 +58,7 @@ int az_nn_conv_block(const void *x, int c_in, const void *weight_ohwi, const voi
  * Same result as az_nn_conv_block up to where the one bf16 rounding sits (weights instead of normalised activations). */
 int az_nn_conv_block2(const void *x, const void *weight_folded_ohwi, const float *t1, const float *t2_scaled, void *y,
                       int64_t batch, float eps, const int64_t *batch_dev, void *stream);
+
 /* The stem with the embedding fused in: az_nn_embed + az_nn_conv_block(c_in 32) as one kernel
  * that builds its tokens from the feature planes (no (batch, 42, 32) tensor in HBM). */
 int az_nn_stem_embed(const float *features, const void *emb_own, const void *emb_opp, const void *pos,

@@ -283,7 +283,7 @@ def test_mfma_conv_block_matches_torch(env):
             assert err.max().item() < 6e-2 and err.mean().item() < 4e-3, (B, cin, err.max().item(), err.mean().item())
 
 
-def test_mfma_conv_block2_matches_torch(env):
+def test_mfma_conv_block2_matches_torch(env, form="az_nn_conv_block2"):
     """nn_conv2.hip (the residual block on 32x32x16 MFMAs with GroupNorm folded into weights and epilogue) against the
     same block in torch, fp32 maths on the same bf16 inputs - same bounds as the first kernel's test - and against the
     first kernel itself (they differ by where one bf16 rounding sits)."""
@@ -304,7 +304,7 @@ def test_mfma_conv_block2_matches_torch(env):
         be = (0.2 * torch.randn(cin, device="cuda", generator=g)).to(bf)
         wf, t1, t2s = fold_block(w, bias, ga, be)
         y = torch.full((B + 2, 42, 64), float("nan"), device="cuda").to(bf)       # two guard samples behind the batch
-        assert L.az_nn_conv_block2(x.data_ptr(), wf.data_ptr(), t1.data_ptr(), t2s.data_ptr(), y.data_ptr(), B, 1e-5, None, s) == 0
+        assert getattr(L, form)(x.data_ptr(), wf.data_ptr(), t1.data_ptr(), t2s.data_ptr(), y.data_ptr(), B, 1e-5, None, s) == 0
         y1 = torch.empty((B, 42, 64), device="cuda", dtype=bf)
         w_ohwi = w.contiguous(memory_format=torch.channels_last)
         assert L.az_nn_conv_block(x.data_ptr(), cin, w_ohwi.data_ptr(), bias.data_ptr(), ga.data_ptr(), be.data_ptr(), 1,
@@ -328,8 +328,8 @@ def test_mfma_conv_block2_matches_torch(env):
     # a compact batch whose size only the device knows
     n_dev = torch.tensor([700], dtype=torch.int64, device="cuda")
     y = torch.full((1027, 42, 64), float("nan"), device="cuda").to(bf)
-    assert L.az_nn_conv_block2(x[:1027].data_ptr(), wf.data_ptr(), t1.data_ptr(), t2s.data_ptr(), y.data_ptr(), 1027, 1e-5,
-                               n_dev.data_ptr(), s) == 0
+    assert getattr(L, form)(x[:1027].data_ptr(), wf.data_ptr(), t1.data_ptr(), t2s.data_ptr(), y.data_ptr(), 1027, 1e-5,
+                            n_dev.data_ptr(), s) == 0
     torch.cuda.synchronize()
     assert torch.isnan(y[700:].float()).all() and torch.equal(y[:700].view(torch.int16), out[:700].to(bf).view(torch.int16))
 

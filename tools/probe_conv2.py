@@ -71,7 +71,7 @@ def timed(fn, n=20):
 
 
 if len(sys.argv) > 3:                 # under a profiler: a few launches of one kernel
-    fn = v1 if sys.argv[3] == "v1" else v2
+    fn = {"v1": v1, "v2": v2}[sys.argv[3]]
     for _ in range(5):
         fn()
     torch.cuda.synchronize()
@@ -82,10 +82,10 @@ else:
         a, c = timed(v1), timed(v2)
         print("round %d: %d leaves  v1 %6.1f us (%4.1f %% of 2.5 PF)   v2 %6.1f us (%4.1f %%)   dbg=%s" %
               (r, B, a, flops / (a * 1e-6) / 2.5e15 * 100, c, flops / (c * 1e-6) / 2.5e15 * 100, os.environ.get("AZ_NN_CONV2_DBG", "0")), flush=True)
-    st = np.zeros(256 * 8 * 4, dtype=np.uint64)
+    st = np.zeros(256 * 4 * 4, dtype=np.uint64)
     L.az_nn_conv2_stamps.argtypes = [C.c_void_p, C.c_int]
     L.az_nn_conv2_stamps(st.ctypes.data, st.size)
-    st = st.reshape(2048, 4).astype(np.float64)
+    st = st.reshape(1024, 4).astype(np.float64)
     st = st[st[:, 2] > 0]
     cyc, ticks, tiles = st[:, 0], st[:, 1], st[:, 2]
     print("   tile loop of the last v2 launch: %.0f cycles per tile (%.1f per MFMA), in-kernel clock %.2f GHz, loop %.1f us, %d-%d tiles per workgroup" %
