@@ -1031,9 +1031,11 @@ __global__ void __launch_bounds__(WAVE) k_backprop(TreeArena ar, LeafBuf lf, Sea
                             HotRec h = empty_rec();
                             h.prior = prior; h.meta = static_cast<uint32_t>(my_action);
                             hot[used + sub] = h;
-                            ColdRec cr;
-                            cr.w_draw = 0.f; cr.noise = noise; cr.parent = leaf; cr.reserved = 0;
-                            cold[used + sub] = cr;
+                            if (root_leaf) {                        // cold record: see k_backprop_spread
+                                ColdRec cr;
+                                cr.w_draw = 0.f; cr.noise = noise; cr.parent = leaf; cr.reserved = 0;
+                                cold[used + sub] = cr;
+                            }
                         }
                         if (sub == owner) {
                             lm = (lm & ~META_NEDGE_MASK) | META_EXPANDED |
@@ -1062,10 +1064,11 @@ __global__ void __launch_bounds__(WAVE) k_backprop(TreeArena ar, LeafBuf lf, Sea
                 }
                 const int slot = path[j];
                 HotRec h = hot[slot];
+                const float dr = h.n_visits != 0 ? cold[slot].w_draw : 0.0f;   // first backup through a node: zero
                 h.n_visits += 1; h.w_p1 += b; h.w_p2 += c; h.m_sum += mm;
                 hot[slot].n_visits = h.n_visits;
                 hot[slot].w_p1 = h.w_p1; hot[slot].w_p2 = h.w_p2; hot[slot].m_sum = h.m_sum;
-                cold[slot].w_draw += a;
+                cold[slot].w_draw = dr + a;
                 ++n_backup;
             }
         }
@@ -1142,7 +1145,7 @@ __global__ void __launch_bounds__(WAVE) k_backprop_batched(TreeArena ar, LeafBuf
             mine[k] = sub < len[k];
             const int slot = mine[k] ? pslot[k] : 0;
             rec[k] = hot[slot];
-            cdraw[k] = cold[slot].w_draw;
+            cdraw[k] = (mine[k] && rec[k].n_visits != 0) ? cold[slot].w_draw : 0.0f;   // first backup through a node: zero
             leaf_meta[k] = len[k] > 0 ? hot[leaf[k]].meta : 0u;
             nv[k] = G::num_valid(ls[k]);
             my_action[k] = sub < nv[k] ? G::nth_valid(ls[k], sub) : -1;
@@ -1241,9 +1244,11 @@ __global__ void __launch_bounds__(WAVE) k_backprop_batched(TreeArena ar, LeafBuf
                             HotRec h = empty_rec();
                             h.prior = prior; h.meta = static_cast<uint32_t>(my_action[k]);
                             hot[used + sub] = h;
-                            ColdRec cr;
-                            cr.w_draw = 0.f; cr.noise = noise; cr.parent = leaf[k]; cr.reserved = 0;
-                            cold[used + sub] = cr;
+                            if (root_leaf) {                        // cold record: see k_backprop_spread
+                                ColdRec cr;
+                                cr.w_draw = 0.f; cr.noise = noise; cr.parent = leaf[k]; cr.reserved = 0;
+                                cold[used + sub] = cr;
+                            }
                         }
                         if (sub == owner) {
                             const uint32_t lm = (leaf_meta[k] & ~META_NEDGE_MASK) | META_EXPANDED |
@@ -1288,10 +1293,11 @@ __global__ void __launch_bounds__(WAVE) k_backprop_batched(TreeArena ar, LeafBuf
                 }
                 const int slot = lf.path[flat * G::MAX_PATH + j];
                 HotRec h = hot[slot];
+                const float dr = h.n_visits != 0 ? cold[slot].w_draw : 0.0f;   // first backup through a node: zero
                 h.n_visits += 1; h.w_p1 += b; h.w_p2 += c; h.m_sum += mm;
                 hot[slot].n_visits = h.n_visits;
                 hot[slot].w_p1 = h.w_p1; hot[slot].w_p2 = h.w_p2; hot[slot].m_sum = h.m_sum;
-                cold[slot].w_draw += a;
+                cold[slot].w_draw = dr + a;
                 ++n_backup;
             }
         }
@@ -1314,6 +1320,266 @@ __global__ void __launch_bounds__(WAVE) k_backprop_batched(TreeArena ar, LeafBuf
     static_assert((WAVE / G::LANES) * KMAX * G::MAX_PATH < 65536, "the backup-node counter of a wavefront is a 16-bit field");
     {
         const unsigned tot = wave_sum_u32(n_backup | (sub == 0 ? (n_exp << 16) | (n_dup << 24) : 0u));
+        if (lane == 0) {
+            unsigned long long *c = counters + (blockIdx.x % CNT_STRIPES) * CNT_N;
+            if ((tot >> 16) & 0xffu) atomicAdd(&c[CNT_EXPANSIONS], static_cast<unsigned long long>((tot >> 16) & 0xffu));
+            if (tot >> 24) atomicAdd(&c[CNT_DUP], static_cast<unsigned long long>(tot >> 24));
+            if (tot & 0xffffu) atomicAdd(&c[CNT_BACKUP], static_cast<unsigned long long>(tot & 0xffffu));
+        }
+    }
+}
+
+// The virtual-loss call with the K leaves of a tree SPREAD over K groups of lanes (KG = K rounded up to a power of
+// two; lane = tree_in_wave * KG * LANES + k * LANES + depth): four times the wavefronts of k_backprop_batched at
+// K = 4, each with a quarter of the instruction stream, so a SIMD has four wavefronts to switch between while
+// records are in flight instead of one.  What k_backprop_batched kept in KMAX-unrolled registers is exchanged
+// between the groups of a tree (one ds_bpermute per value and partner):
+//   * a node that several paths share sits at the same depth of each of them, i.e. at the same `sub` of several
+//     groups: the first group that holds it owns it, takes the record and adds the contributions of the groups
+//     k' >= k in ascending k' - the order of the reference's sequential read-modify-writes (MCTS.h:381-402), so
+//     the float sums are bit-identical - and writes it back once;
+//   * the allocation of child blocks is a serial scan over k (MCTS.h:329-375: a leaf selected twice is expanded by
+//     its first k only; a block that does not fit raises the overflow flag and is skipped); every lane runs the
+//     K-step scan on the exchanged (leaf, edge count, candidate) triples and keeps its own group's outcome.
+// Levels past the first LANES of a path (rare) are read-modify-written in memory, group after group.
+// Expansion no longer writes the 16-byte cold record of a child that is not the root's: its noise is read for the
+// root's children only (re-rooting writes it, k_prune) and w_draw only once n_visits != 0 - the first backup
+// through a node takes w_draw as zero instead of loading it.
+template <class G, bool FUSED, int KG, int WPB>
+__global__ void __launch_bounds__(WAVE * WPB) k_backprop_spread(TreeArena ar, LeafBuf lf, SearchParams p, int K,
+                                                                EvalIn in, unsigned long long *counters, int *err)
+{
+    constexpr int L = G::LANES;
+    constexpr int A = G::ACTIONS;
+    constexpr int TPW = WAVE / (L * KG);
+    static_assert(L * KG <= WAVE && L <= 8, "groups of a tree share a wavefront");
+    const int lane = threadIdx.x % WAVE;
+    const int sub = lane % L;
+    const int k = (lane / L) % KG;
+    const int tw = lane / (L * KG);
+    const int base = tw * (L * KG) + sub;                           // lane of group 0 at this depth
+    const int tree = (blockIdx.x * WPB + threadIdx.x / WAVE) * TPW + tw;
+    const bool live = tree < ar.B;
+    const int t = live ? tree : 0;
+    HotRec *hot = ar.hot + tree_base(ar, t);
+    ColdRec *cold = ar.cold + tree_base(ar, t);
+    const bool on = live && k < K;
+    const size_t flat = static_cast<size_t>(t) * K + (on ? k : 0);
+    unsigned n_exp = 0, n_dup = 0, n_backup = 0;
+
+    // ---- round 1: what selection left behind for this group's leaf, and this lane's path slot
+    const int len = on ? lf.path_len[flat] : 0;
+    const int leaf = lf.slot[flat];
+    const uint8_t lflags = lf.flags[flat];
+    GameState ls;
+    ls.bb0 = lf.bb0[flat]; ls.bb1 = lf.bb1[flat]; ls.turn = lf.turn[flat]; ls.aux = lf.aux[flat];
+    const int sym = in.sym ? in.sym[flat] : lf.sym[flat];
+    const int pslot_raw = lf.path[flat * G::MAX_PATH + sub];
+    float ev_d, ev_w, ev_l;
+    if (FUSED) { ev_d = in.wdl_rel[flat * 3]; ev_w = in.wdl_rel[flat * 3 + 1]; ev_l = in.wdl_rel[flat * 3 + 2]; }
+    else       { ev_d = in.d[flat]; ev_w = in.p1w[flat]; ev_l = in.p2w[flat]; }
+    const float ev_ml = in.moves_left[flat];
+    const int used0 = ar.used[t];
+    const bool is_term_host = FUSED ? false : in.is_term[flat] != 0;
+
+    // ---- round 2: this lane's node of the path, the leaf's flags, the policy entry of this lane's move
+    const bool mine = sub < len;
+    const int pslot = mine ? pslot_raw : 0;
+    HotRec rec = hot[pslot];
+    float cdraw = (mine && rec.n_visits != 0) ? cold[pslot].w_draw : 0.0f;
+    const uint32_t leaf_meta = len > 0 ? hot[leaf].meta : 0u;
+    const int nv = G::num_valid(ls);
+    const int my_action = sub < nv ? G::nth_valid(ls, sub) : -1;
+    const float my_pol = my_action >= 0 ? in.policy[flat * A + G::policy_index(sym, my_action)] : 0.0f;
+
+    // ---- the leaf's value as the tree takes it (MCTS_cpp.py:23-30, 275-282; MCTS.h:412,608)
+    bool term;
+    float wd, w1, w2, ml;
+    if (FUSED) {
+        term = (lflags & LEAF_TERMINAL) != 0;
+        if (term) {
+            const int code = (lflags >> LEAF_RESULT_SHIFT) & 3;
+            wd = code == 0 ? 1.0f : 0.0f; w1 = code == 1 ? 1.0f : 0.0f; w2 = code == 2 ? 1.0f : 0.0f;
+            ml = 0.0f;
+        } else {
+            wd = ev_d;
+            w1 = (ls.turn == 1) ? ev_w : ev_l;
+            w2 = (ls.turn == 1) ? ev_l : ev_w;
+            ml = ev_ml;
+        }
+    } else {
+        term = is_term_host;
+        wd = ev_d; w1 = ev_w; w2 = ev_l; ml = ev_ml;
+    }
+    if (term) ml = G::terminal_aux(ls, p);
+    const bool vl_on = len > 0 && (lflags & LEAF_VL_APPLIED) != 0;
+    const bool cand = len > 0 && !term && !(leaf_meta & META_EXPANDED);   // would be expanded if no earlier k took the leaf
+    const bool dup0 = len > 0 && !term && (leaf_meta & META_EXPANDED);    // expanded before this call: a duplicate
+
+    // this lane's contribution to its node: the node `dist` levels above the leaf receives the auxiliary value
+    // after `dist` per-ply steps and the value decayed dist times (MCTS.h:381-402)
+    const float g = p.value_decay;
+    const float cst = (1.0f - g) * (1.0f / 3.0f);
+    float ca = wd, cb = w1, cc = w2, cm = ml;
+    {
+        const int dist = len - 1 - sub;
+        for (int i = 0; i < dist; ++i) {
+            if (G::AUX_PLUS_ONE) cm += 1.0f;
+            if (G::AUX_NEGATE) cm = -cm;
+            if (g < 1.0f) { ca = fmaf(ca, g, cst); cb = fmaf(cb, g, cst); cc = fmaf(cc, g, cst); }
+        }
+    }
+
+    // ---- exchange between the groups of the tree
+    const int word = (mine ? 1 : 0) | (vl_on ? 2 : 0) | (cand ? 4 : 0) | (nv << 8);
+    int q_slot[KG], q_word[KG], q_leaf[KG];
+    float q_a[KG], q_b[KG], q_c[KG], q_m[KG];
+#pragma unroll
+    for (int q = 0; q < KG; ++q) {
+        const int src = base + q * L;
+        q_slot[q] = __shfl(pslot, src, WAVE);
+        q_word[q] = __shfl(word, src, WAVE);
+        q_leaf[q] = __shfl(leaf, src, WAVE);
+        q_a[q] = __shfl(ca, src, WAVE); q_b[q] = __shfl(cb, src, WAVE);
+        q_c[q] = __shfl(cc, src, WAVE); q_m[q] = __shfl(cm, src, WAVE);
+    }
+
+    // ---- allocation scan over k (every lane, same result within a tree)
+    int used = used0;
+    bool exp_me = false, dup_me = dup0, ovf_me = false;
+    int off_me = 0;
+    {
+        bool exp_q[KG];
+#pragma unroll
+        for (int q = 0; q < KG; ++q) {
+            exp_q[q] = false;
+            const bool c_q = (q_word[q] & 4) != 0;
+            const int nv_q = (q_word[q] >> 8) & 0xff;
+            bool was = false;
+#pragma unroll
+            for (int r = 0; r < KG; ++r)
+                if (r < q && exp_q[r] && q_leaf[r] == q_leaf[q]) was = true;
+            if (c_q && was) { if (q == k) dup_me = true; }
+            else if (c_q) {
+                if (static_cast<int64_t>(used) + nv_q > ar.S) { if (q == k) ovf_me = true; }
+                else {
+                    exp_q[q] = true;
+                    if (q == k) { exp_me = true; off_me = used; }
+                    used += nv_q;
+                }
+            }
+        }
+    }
+
+    if (on) {
+        // ---- virtual loss comes off every node of every recorded path (MCTS.h:561-581)
+        if (vl_on) {
+            for (int j = sub + L; j < len; j += L) atomicSub(&hot[lf.path[flat * G::MAX_PATH + j]].n_inflight, p.vl_count);
+            if (sub == 0) lf.flags[flat] = lflags & static_cast<uint8_t>(~LEAF_VL_APPLIED);
+        }
+
+        // ---- expansion of this group's leaf (MCTS.h:329-375)
+        if (ovf_me && sub == 0) atomicOr(err, ERR_ARENA_OVERFLOW);
+        if (dup_me && sub == 0) ++n_dup;
+    }
+    {
+        // (the shuffles of the group's ordered sums need every lane of the group: outside the branches)
+        float psum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < L - 1; ++i) psum += __shfl(my_pol, i, L);
+        const float prior = my_pol / (psum + 1e-8f);                // MCTS.h:370
+        const bool root_leaf = (len == 1);                          // leaf.parent == -1, MCTS.h:349
+        float noise = 0.0f;
+        if (on && exp_me && root_leaf && p.alpha > 0.0f && sub < nv) {
+            if (in.root_noise) {
+                noise = in.root_noise[static_cast<size_t>(t) * A + sub];
+            } else {
+                DevRng rg(p.seed, *p.call_ptr, static_cast<uint64_t>(t), static_cast<uint64_t>(sub) + 16);
+                noise = rg.gamma(p.alpha);
+            }
+        }
+        if (p.alpha > 0.0f && !in.root_noise) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < L - 1; ++i) sum += __shfl(noise, i, L);   // lanes >= nv hold 0: the same sum as over nv terms
+            if (on && exp_me && root_leaf) noise = noise * (1.0f / (sum + 1e-8f));
+        }
+        if (on && exp_me) {
+            if (sub < nv) {
+                HotRec h = empty_rec();
+                h.prior = prior; h.meta = static_cast<uint32_t>(my_action);
+                hot[off_me + sub] = h;
+                if (root_leaf) {
+                    ColdRec cr;
+                    cr.w_draw = 0.f; cr.noise = noise; cr.parent = leaf; cr.reserved = 0;
+                    cold[off_me + sub] = cr;
+                }
+            }
+            if (sub == (len - 1) % L) {
+                hot[leaf].child_off = off_me;
+                hot[leaf].meta = (leaf_meta & ~META_NEDGE_MASK) | META_EXPANDED | (static_cast<uint32_t>(nv) << META_NEDGE_SHIFT);
+            }
+            if (sub == 0) ++n_exp;
+        }
+    }
+    if (on) {
+        // ---- statistics: the owner of a node adds the contributions in ascending k and writes the node back once
+        bool own = mine;                                            // the first group that holds this node owns it
+        int infl = 0;
+#pragma unroll
+        for (int q = 0; q < KG; ++q) {
+            const bool same = (q_word[q] & 1) && q_slot[q] == pslot;
+            if (q < k && same) own = false;
+            if (same && (q_word[q] & 2)) infl += p.vl_count;
+        }
+        if (mine) ++n_backup;
+        if (own) {
+#pragma unroll
+            for (int q = 0; q < KG; ++q) {
+                const bool same = (q_word[q] & 1) && q_slot[q] == pslot;
+                if (q >= k && same) {
+                    rec.n_visits += 1; rec.w_p1 += q_b[q]; rec.w_p2 += q_c[q]; rec.m_sum += q_m[q];
+                    cdraw += q_a[q];
+                }
+            }
+            HotRec *d = hot + pslot;
+            d->n_visits = rec.n_visits; d->n_inflight = rec.n_inflight - infl;
+            d->w_p1 = rec.w_p1; d->w_p2 = rec.w_p2; d->m_sum = rec.m_sum;
+            cold[pslot].w_draw = cdraw;
+        }
+        if (sub == 0 && k == 0 && used != used0) ar.used[t] = used;
+    }
+    // ---- levels past the first LANES of a path: in memory, group after group (two groups may share such a node)
+    if (__any(on && len > L)) {
+#pragma unroll 1
+        for (int q = 0; q < KG; ++q) {
+            if (on && q == k) {
+                for (int j = sub + L; j < len; j += L) {
+                    const int dist = len - 1 - j;
+                    float a = wd, b = w1, c = w2, mm = ml;
+                    for (int i = 0; i < dist; ++i) {
+                        if (G::AUX_PLUS_ONE) mm += 1.0f;
+                        if (G::AUX_NEGATE) mm = -mm;
+                        if (g < 1.0f) { a = fmaf(a, g, cst); b = fmaf(b, g, cst); c = fmaf(c, g, cst); }
+                    }
+                    const int slot = lf.path[flat * G::MAX_PATH + j];
+                    HotRec h = hot[slot];
+                    const float dr = h.n_visits != 0 ? cold[slot].w_draw : 0.0f;
+                    h.n_visits += 1; h.w_p1 += b; h.w_p2 += c; h.m_sum += mm;
+                    hot[slot].n_visits = h.n_visits;
+                    hot[slot].w_p1 = h.w_p1; hot[slot].w_p2 = h.w_p2; hot[slot].m_sum = h.m_sum;
+                    cold[slot].w_draw = dr + a;
+                    ++n_backup;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_s_waitcnt(0);
+        }
+    }
+    static_assert((WAVE / G::LANES) < 256, "expansion / duplicate counters of a wavefront are 8-bit fields");
+    static_assert((WAVE / G::LANES) * G::MAX_PATH < 65536, "the backup-node counter of a wavefront is a 16-bit field");
+    {
+        const unsigned tot = wave_sum_u32(n_backup | (n_exp << 16) | (n_dup << 24));
         if (lane == 0) {
             unsigned long long *c = counters + (blockIdx.x % CNT_STRIPES) * CNT_N;
             if ((tot >> 16) & 0xffu) atomicAdd(&c[CNT_EXPANSIONS], static_cast<unsigned long long>((tot >> 16) & 0xffu));
@@ -1521,6 +1787,7 @@ __global__ void __launch_bounds__(WAVE) k_prune(TreeArena ar, SearchParams p, co
             atomicMax(max_live, ar.used[t]);
         }
         const int want0 = (p.alpha > 0.0f) ? nE0 : 0;                   // apply_root_noise, MCTS.h:113-132
+        if (want0 == 0 && lane < nE0) cold[noff0 + lane].noise = 0.0f;  // expansion writes the noise of the root's children only
         if (!dev_noise) {
             if (lane == 0) noise_req[t] = want0;
         } else if (want0 > 0 && replay_noise != nullptr) {
@@ -1586,6 +1853,7 @@ __global__ void __launch_bounds__(WAVE) k_prune(TreeArena ar, SearchParams p, co
         atomicMax(max_live, used);
     }
     const int want = (p.alpha > 0.0f) ? nE : 0;                        // apply_root_noise, MCTS.h:113-132
+    if (want == 0 && lane < nE) ncold[noff + lane].noise = 0.0f;
     if (!dev_noise) {
         if (lane == 0) noise_req[t] = want;
     } else if (want > 0 && replay_noise != nullptr) {
@@ -1863,6 +2131,24 @@ void launch_backprop(int game, TreeArena ar, LeafBuf lf, SearchParams p, int K, 
                      EvalIn in, unsigned long long *counters, int *err, hipStream_t s)
 {
     static const bool v1 = getenv("AZ_BACKPROP_V1") != nullptr && getenv("AZ_BACKPROP_V1")[0] == '1';
+    static const bool no_spread = getenv("AZ_BACKPROP_SPREAD") != nullptr && getenv("AZ_BACKPROP_SPREAD")[0] == '0';
+    if (game == Connect4Dev::GAME_ID && vl && K >= 2 && K <= 8 && !v1 && !no_spread) {
+        using G = Connect4Dev;
+        const int kg = K <= 2 ? 2 : (K <= 4 ? 4 : 8);
+        constexpr int W = 1;                                        // wavefronts per workgroup (4: 19.6 us against 19.1)
+        const dim3 grid(grid_for(ar.B, W * WAVE / (G::LANES * kg))), block(W * WAVE);
+        if (kg == 2) {
+            if (fused) hipLaunchKernelGGL((k_backprop_spread<G, true, 2, W>), grid, block, 0, s, ar, lf, p, K, in, counters, err);
+            else       hipLaunchKernelGGL((k_backprop_spread<G, false, 2, W>), grid, block, 0, s, ar, lf, p, K, in, counters, err);
+        } else if (kg == 4) {
+            if (fused) hipLaunchKernelGGL((k_backprop_spread<G, true, 4, W>), grid, block, 0, s, ar, lf, p, K, in, counters, err);
+            else       hipLaunchKernelGGL((k_backprop_spread<G, false, 4, W>), grid, block, 0, s, ar, lf, p, K, in, counters, err);
+        } else {
+            if (fused) hipLaunchKernelGGL((k_backprop_spread<G, true, 8, W>), grid, block, 0, s, ar, lf, p, K, in, counters, err);
+            else       hipLaunchKernelGGL((k_backprop_spread<G, false, 8, W>), grid, block, 0, s, ar, lf, p, K, in, counters, err);
+        }
+        return;
+    }
     if (K <= 4 && !v1) {
         AZ_DISPATCH(game, {
             const int tpw = trees_per_wave(G::LANES);
