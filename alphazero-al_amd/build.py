@@ -59,6 +59,7 @@ def build_engine(force=False):
         src, obj = os.path.join(CSRC, n + ".hip"), os.path.join(objdir, n + ".o")
         if force or _stale(obj, [src] + headers):
             jobs.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+                         *os.environ.get("AZ_EXTRA_CFLAGS", "").split(),      # experiments only (e.g. -DAZ_OTH_EXPERIMENTS)
                          "-I", INC, "-I", CSRC, "-c", src, "-o", obj])
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as pool:
