@@ -72,6 +72,14 @@ def test_vs_oracle_odd_batch_and_k(mcts_cpp):
     _side_by_side(mcts_cpp, dict(S.ACTOR_CFG, vl_count=3, c_base=335.0), 77, 67, 5, 6, 20, seed=5, rng_seed=2)
 
 
+@pytest.mark.parametrize("K", [2, 3, 7, 8])
+def test_vs_oracle_backup_lane_group_sizes(mcts_cpp, K):
+    """k_backprop_spread gives every (tree, k) its own lane group, K rounded up to 2, 4 or 8 groups per tree:
+    every group count, trees that do not fill the last wavefront, paths deeper than the eight lanes of a group
+    (400 simulations on few trees), duplicate leaves and terminal leaves (20 plies into the game)."""
+    _side_by_side(mcts_cpp, dict(S.ACTOR_CFG, c_base=500.0), 13, 400, K, 3, 20, seed=11 + K, rng_seed=4)
+
+
 def test_vs_oracle_arena_growth(mcts_cpp):
     # 800 simulations x 7 plies outgrow the initial 4096-record arenas several times
     _side_by_side(mcts_cpp, dict(S.DET_CFG, c_base=4000.0), 12, 800, 4, 7, 4, seed=None, rng_seed=3)
