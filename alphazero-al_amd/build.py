@@ -43,6 +43,11 @@ def _run(cmd):
     subprocess.check_call(cmd)
 
 
+# nn_stem: MFMA results in VGPRs (its SiLU reads every accumulator element right away; from AGPRs that is one
+# v_accvgpr_read each)
+PER_FILE_FLAGS = {"nn_stem": ("-mllvm", "-amdgpu-mfma-vgpr-form=1")}
+
+
 def build_engine(force=False):
     """One object per .hip source (compiled in parallel, rebuilt only when that source or a header
     changed), linked into lib/libaz_mcts.so.  No device code crosses translation units."""
@@ -51,7 +56,7 @@ def build_engine(force=False):
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     out = os.path.join(LIB, "libaz_mcts.so")
-    names = ("kernels", "tt_kernels", "engine", "nn_kernels", "nn_conv", "nn_conv2", "nn_attn", "nn_heads", "nn_model", "nn_othello", "nn_othello_heads")
+    names = ("kernels", "tt_kernels", "engine", "nn_kernels", "nn_conv", "nn_conv2", "nn_stem", "nn_attn", "nn_heads", "nn_model", "nn_othello", "nn_othello_heads")
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     headers = _headers()
     jobs = []
@@ -60,6 +65,7 @@ def build_engine(force=False):
         if force or _stale(obj, [src] + headers):
             jobs.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
                          *os.environ.get("AZ_EXTRA_CFLAGS", "").split(),      # experiments only (e.g. -DAZ_OTH_EXPERIMENTS)
+                         *PER_FILE_FLAGS.get(n, ()),
                          "-I", INC, "-I", CSRC, "-c", src, "-o", obj])
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as pool:

@@ -168,6 +168,7 @@ int az_nn_model_create(const az_nn_model_weights *w, az_nn_model **out)
 {
     if (w == nullptr || out == nullptr) return 1;
     if (w->n_blocks < 0 || w->n_blocks > AZ_NN_MAX_BLOCKS) return 1;
+    if ((w->stem_frag == nullptr) != (w->stem_pmap == nullptr)) return 1;
     const void *need[] = {w->emb_own, w->emb_opp, w->pos, w->stem_w, w->stem_b, w->pre_w, w->qkvg_w,
                           w->qn_w, w->kn_w, w->o_w, w->heads.p_norm, w->heads.d_val_w};
     for (const void *p : need)
@@ -320,9 +321,15 @@ static int forward_impl(const az_nn_model *m, const float *features, const az_nn
     auto begin = [&](int kd) { if (timed && slot[kd] >= 0) (void)hipEventRecord(g_prof.start[kd][slot[kd]], hs); };
     auto end = [&](int kd) { if (timed && slot[kd] >= 0) (void)hipEventRecord(g_prof.stop[kd][slot[kd]], hs); };
     begin(AZ_NN_PROFILE_STEM);
-    int rc = positions != nullptr
-        ? az_nn_stem_embed_positions(positions, w.emb_own, w.emb_opp, w.pos, w.stem_w, w.stem_b, a, batch, rows, n_rows, stream)
-        : az_nn_stem_embed(features, w.emb_own, w.emb_opp, w.pos, w.stem_w, w.stem_b, a, batch, rows, n_rows, stream);
+    int rc;
+    if (w.stem_frag != nullptr && w.stem_pmap != nullptr)
+        rc = positions != nullptr
+            ? az_nn_stem_folded_positions(positions, w.stem_frag, w.stem_pmap, a, batch, rows, n_rows, stream)
+            : az_nn_stem_folded(features, w.stem_frag, w.stem_pmap, a, batch, rows, n_rows, stream);
+    else
+        rc = positions != nullptr
+            ? az_nn_stem_embed_positions(positions, w.emb_own, w.emb_opp, w.pos, w.stem_w, w.stem_b, a, batch, rows, n_rows, stream)
+            : az_nn_stem_embed(features, w.emb_own, w.emb_opp, w.pos, w.stem_w, w.stem_b, a, batch, rows, n_rows, stream);
     end(AZ_NN_PROFILE_STEM);
     for (int i = 0; rc == 0 && i < w.n_blocks; ++i) {
         if (i == 0) begin(AZ_NN_PROFILE_CONV);

@@ -48,6 +48,7 @@ def glue():
             L.az_nn_attn_block.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, f32, vp, vp]
             L.az_nn_heads.argtypes = [vp, C.POINTER(HeadsWeights), vp, vp, vp, vp, i64, f32, vp, vp, vp]
             L.az_nn_stem_embed.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp]
+            L.az_nn_stem_folded.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp]
             L.az_nn_model_create.argtypes = [C.POINTER(ModelWeights), C.POINTER(vp)]
             L.az_nn_model_destroy.argtypes = [vp]
             L.az_nn_model_destroy.restype = None
@@ -81,6 +82,36 @@ def fold_block(w, bias, gamma, beta):
     return (wf.contiguous(memory_format=torch.channels_last), t1.contiguous(), (t2 * 1.4426950408889634).contiguous())
 
 
+def fold_stem(weight, bias, emb_own, emb_opp, pos_map):
+    """What az_nn_stem_folded (include/az_nn.h, nn_stem.hip) takes instead of the embedding tables and the stem's weight:
+    the tokens are own * e_own + opp * e_opp + pos with own / opp in {0, 1} (Network.py:226-239) and the convolution is
+    linear, so  conv(tokens)[o, cell] + bias = pmap[cell][o] + sum over the taps inside the board of
+    own[n] * T[o][2 tap] + opp[n] * T[o][2 tap + 1].  weight (O, E, 3, 3) and bias are rounded to bf16 as the reference's
+    autocast rounds them; the embeddings stay fp32 (the reference adds them in fp32).  Returns (w_frag bf16 [2][4][64][8]:
+    T split into a bf16 high and low part in MFMA fragment order, pmap float32 [48][68])."""
+    w = weight.to(torch.bfloat16).float()                           # (64, E, 3, 3)
+    out_c = w.shape[0]
+    assert out_c == 64 and tuple(w.shape[2:]) == (3, 3) and pos_map.shape[0] == CELLS
+    a = torch.einsum("ocyx,c->oyx", w, emb_own.float()).reshape(out_c, 9)
+    b = torch.einsum("ocyx,c->oyx", w, emb_opp.float()).reshape(out_c, 9)
+    t = torch.zeros((out_c, 32), dtype=torch.float32, device=w.device)
+    t[:, 0:18:2] = a
+    t[:, 1:18:2] = b
+    hi = t.to(torch.bfloat16)
+    lo = (t - hi.float()).to(torch.bfloat16)
+    lane = torch.arange(64, device=w.device)
+    # row r of channel tile i is channel 32 (i // 2) + 8 (r // 4) + 4 (i % 2) + r % 4: a lane's rows of two neighbouring
+    # tiles are eight consecutive channels (one 16-byte store)
+    ti, r = torch.arange(4, device=w.device).view(4, 1), (lane & 15).view(1, 64)
+    rows = 32 * (ti // 2) + 8 * (r // 4) + 4 * (ti % 2) + r % 4                                     # (4, 64): channel of [tile][lane]
+    cols = ((lane >> 4) * 8).view(64, 1) + torch.arange(8, device=w.device).view(1, 8)              # (64, 8): k of [lane][j]
+    frag = torch.stack([part[rows.view(4, 64, 1), cols.view(1, 64, 8)] for part in (hi, lo)]).contiguous()    # (2, 4, 64, 8)
+    pm = torch.nn.functional.conv2d(pos_map.float().t().reshape(1, -1, 6, COLS), w, bias.to(torch.bfloat16).float(), padding=1)
+    pmap = torch.zeros((48, 68), dtype=torch.float32, device=w.device)
+    pmap[:CELLS, :out_c] = pm.reshape(out_c, CELLS).t()
+    return frag, pmap.contiguous()
+
+
 class HeadsWeights(C.Structure):
     """az_nn_heads_weights of include/az_nn.h"""
     _PTRS = ("p_norm", "p_gate_w", "p_fc_w", "p_fc_b", "p_out_w", "d_pool_norm", "d_pool_w", "d_pool_b", "d_norm",
@@ -96,7 +127,7 @@ class ModelWeights(C.Structure):
     _fields_ = ([(n, C.c_void_p) for n in ("emb_own", "emb_opp", "pos", "stem_w", "stem_b")] + [("n_blocks", C.c_int32)] +
                 [(n, C.c_void_p * MAX_BLOCKS) for n in ("block_w", "block_b", "block_gamma", "block_beta")] +
                 [(n, C.c_void_p) for n in ("pre_w", "qkvg_w", "qn_w", "kn_w", "o_w")] +
-                [("heads", HeadsWeights), ("eps", C.c_float)])
+                [("heads", HeadsWeights), ("eps", C.c_float), ("stem_frag", C.c_void_p), ("stem_pmap", C.c_void_p)])
 
 
 class FastConnect4Net(torch.nn.Module):
@@ -121,6 +152,13 @@ class FastConnect4Net(torch.nn.Module):
             return c(w).contiguous(memory_format=torch.channels_last)
         self.register_buffer("stem_w", conv_w(sd["hidden.0.weight"]))
         self.register_buffer("stem_b", c(sd["hidden.0.bias"]))
+        # the stem as a K = 18 GEMM on the 0/1 planes (nn_stem.hip); AZ_STEM_FOLDED=0: embedding + K = 288 convolution
+        self.folded_stem = os.environ.get("AZ_STEM_FOLDED", "1") != "0" and sd["hidden.0.weight"].shape[0] == 64
+        if self.folded_stem:
+            frag, pmap = fold_stem(sd["hidden.0.weight"], sd["hidden.0.bias"], sd["piece_emb.weight"][0], sd["piece_emb.weight"][1],
+                                   sd["pos_emb.weight"][sd["orbit_map"].long()])
+            self.register_buffer("stem_frag", frag)
+            self.register_buffer("stem_pmap", pmap)
         self.h_dim = sd["hidden.0.weight"].shape[0]
         self.res = []
         i = 2
@@ -192,6 +230,8 @@ class FastConnect4Net(torch.nn.Module):
                     getattr(w, field)[i] = getattr(self, name).data_ptr()
             w.heads = self._heads_w
             w.eps = 1e-5
+            if self.folded_stem:
+                w.stem_frag, w.stem_pmap = self.stem_frag.data_ptr(), self.stem_pmap.data_ptr()
             h = C.c_void_p()
             if glue().az_nn_model_create(C.byref(w), C.byref(h)) != 0:
                 raise RuntimeError("az_nn_model_create refused the weights")
@@ -296,8 +336,11 @@ class FastConnect4Net(torch.nn.Module):
         x = x.contiguous().float()
         t = torch.empty((bsz, CELLS, c_dim), dtype=bf, device=dev)
         # embedding + stem convolution in one kernel: the tokens are built in LDS
-        L.az_nn_stem_embed(x.data_ptr(), self.emb_own.data_ptr(), self.emb_opp.data_ptr(), self.pos.data_ptr(),
-                           self.stem_w.data_ptr(), self.stem_b.data_ptr(), t.data_ptr(), bsz, gp, np_, s)
+        if self.folded_stem:
+            L.az_nn_stem_folded(x.data_ptr(), self.stem_frag.data_ptr(), self.stem_pmap.data_ptr(), t.data_ptr(), bsz, gp, np_, s)
+        else:
+            L.az_nn_stem_embed(x.data_ptr(), self.emb_own.data_ptr(), self.emb_opp.data_ptr(), self.pos.data_ptr(),
+                               self.stem_w.data_ptr(), self.stem_b.data_ptr(), t.data_ptr(), bsz, gp, np_, s)
         for w, b, g, beta in self.res:
             t2 = torch.empty_like(t)
             L.az_nn_conv_block(t.data_ptr(), c_dim, getattr(self, w).data_ptr(), getattr(self, b).data_ptr(),

@@ -75,6 +75,20 @@ typedef struct az_nn_positions {
 int az_nn_stem_embed_positions(const az_nn_positions *positions, const void *emb_own, const void *emb_opp, const void *pos,
                                const void *weight_ohwi, const void *bias, void *y, int64_t batch, const int32_t *gather,
                                const int64_t *batch_dev, void *stream);
+/* The stem from FOLDED tables (nn_stem.hip): the tokens are own * e_own + opp * e_opp + pos with own / opp in {0, 1} and the
+ * convolution is linear, so the layer is a K = 18 GEMM on a 0/1 operand built from the planes / bitboards plus a per-cell
+ * constant (same inputs, same output as az_nn_stem_embed[_positions], fp32-accurate sums instead of bf16 tokens):
+ *   w_frag  bf16 [2][4][64][8]: the table  T[o][k], k = 2 * tap + plane (tap = 3 * ky + kx; plane 0 own, 1 opponent; k >= 18
+ *           zero),  T[o][2 tap] = sum_c W[o][c][tap] e_own[c],  T[o][2 tap + 1] likewise with e_opp, split into a bf16 high
+ *           part [0] and a bf16 low part [1] (T - high), each in MFMA fragment order: [channel tile i][lane][j] =
+ *           part[32 (i / 2) + 8 (r / 4) + 4 (i % 2) + r % 4][8 (lane >> 4) + j] with r = lane & 15 (the rows of two
+ *           neighbouring tiles that a lane ends up with are eight consecutive channels);
+ *   pmap    float32 [48][68]: rows 0..41, columns 0..63 = conv3x3(pos map, W)[o, cell] + bias[o] (zero padding), the rest 0.
+ * Both come from alphazero-al_amd/src/fast_net.py fold_stem. */
+int az_nn_stem_folded(const float *features, const void *w_frag, const float *pmap, void *y, int64_t batch,
+                      const int32_t *gather, const int64_t *batch_dev, void *stream);
+int az_nn_stem_folded_positions(const az_nn_positions *positions, const void *w_frag, const float *pmap, void *y,
+                                int64_t batch, const int32_t *gather, const int64_t *batch_dev, void *stream);
 /* The whole gated attention block as a single MFMA kernel (nn_attn.hip):
  *   y = x + o_proj(sigmoid(gate) * softmax(qnorm(Q) knorm(K)^T / 4) V),  [Q|K|V|gate] = qkvg(RMSNorm(x))
  * (Network.py:51-93).  x, y (batch, 42, 64); qkvg_w (196, 64) row-major [out][in] with rows
@@ -138,6 +152,8 @@ typedef struct az_nn_model_weights {
     const void *pre_w, *qkvg_w, *qn_w, *kn_w, *o_w;         /* as az_nn_attn_block */
     az_nn_heads_weights heads;                              /* as az_nn_heads */
     float eps;
+    const void *stem_frag;                                  /* as az_nn_stem_folded; both NULL: the stem runs az_nn_stem_embed */
+    const float *stem_pmap;
 } az_nn_model_weights;
 typedef struct az_nn_model az_nn_model;
 int az_nn_model_create(const az_nn_model_weights *w, az_nn_model **out);

@@ -1007,6 +1007,86 @@ def _rand_othello_net(env, seed):
     return net
 
 
+def test_folded_stem_matches_torch_and_the_embedding_stem(env):
+    """az_nn_stem_folded (nn_stem.hip: the stem as a K = 18 GEMM on the 0/1 planes + a per-cell constant, tables from
+    fast_net.fold_stem) against the layer in torch fp32 (embedding, convolution with bf16-rounded weights, SiLU;
+    Network.py:168-170,226-239) - within bf16 output rounding - and against az_nn_stem_embed (bf16 tokens, K = 288),
+    which it must beat in accuracy; planes and bitboards give identical bits; compact batches (gather, device-side count)."""
+    torch = env["torch"]
+    import ctypes as C
+    from src.fast_net import FastConnect4Net, fold_stem, glue
+    from src.az_net import Connect4Net
+    L = glue()
+    vp = C.c_void_p
+    torch.manual_seed(11)
+    mod = Connect4Net(device="cuda").eval()
+    with torch.no_grad():
+        mod.hidden[0].weight.normal_(0.0, 0.08); mod.hidden[0].bias.normal_(0.0, 0.3)
+        mod.piece_emb.weight.normal_(0.0, 1.0); mod.pos_emb.weight.normal_(0.0, 1.0)
+    net = FastConnect4Net.from_module(mod)
+    assert net.folded_stem
+    s = vp(torch.cuda.current_stream().cuda_stream)
+    F = torch.nn.functional
+    bf = lambda t: t.to(torch.bfloat16).float()                                   # noqa: E731
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    for bsz in (1, 3, 4, 1023, 4097):
+        # random legal-looking boards: every cell empty / own / opponent
+        st = torch.randint(0, 3, (bsz, 6, 7), device="cuda", generator=g)
+        feat = torch.zeros((bsz, 3, 6, 7), device="cuda")
+        feat[:, 0] = (st == 1).float(); feat[:, 1] = (st == 2).float(); feat[:, 2] = 1.0
+        y = torch.full((bsz, 42, 64), 7.0, dtype=torch.bfloat16, device="cuda")
+        assert L.az_nn_stem_folded(feat.data_ptr(), net.stem_frag.data_ptr(), net.stem_pmap.data_ptr(), y.data_ptr(), bsz, None, None, s) == 0
+        y_old = torch.empty_like(y)
+        L.az_nn_stem_embed(feat.data_ptr(), net.emb_own.data_ptr(), net.emb_opp.data_ptr(), net.pos.data_ptr(),
+                           net.stem_w.data_ptr(), net.stem_b.data_ptr(), y_old.data_ptr(), bsz, None, None, s)
+        with torch.no_grad():
+            tok = mod.embed(feat)                                                 # (B, 32, 6, 7) fp32
+            want = F.silu(F.conv2d(tok, bf(mod.hidden[0].weight), bf(mod.hidden[0].bias), padding=1))
+        want = want.permute(0, 2, 3, 1).reshape(bsz, 42, 64)
+        torch.cuda.synchronize()
+        err = (y.float() - want).abs() / (1.0 + want.abs())
+        err_old = (y_old.float() - want).abs() / (1.0 + want.abs())
+        # one bf16 rounding of the output: 2^-9 relative; the K = 288 kernel also carries the tokens' rounding
+        assert err.max().item() < 4.5e-3 and err.mean().item() < 8e-4, (bsz, err.max().item(), err.mean().item())
+        assert err.mean().item() <= err_old.mean().item() * 1.02, (bsz, err.mean().item(), err_old.mean().item())
+    # bitboards instead of planes (the native loop's form): identical bits, mirrored ids included
+    bsz = 777
+    h = torch.randint(0, 7, (bsz, 7), device="cuda", generator=g)                 # column heights
+    colour = torch.randint(0, 2, (bsz, 7, 6), device="cuda", generator=g)
+    bb1 = torch.zeros(bsz, dtype=torch.int64, device="cuda"); bb2 = torch.zeros_like(bb1)
+    grid = torch.zeros((bsz, 6, 7), device="cuda")                                # +1 / -1 stones, row 0 on top
+    for c in range(7):
+        for k in range(6):
+            on = h[:, c] > k
+            p1 = on & (colour[:, c, k] == 1)
+            p2 = on & (colour[:, c, k] == 0)
+            bb1 |= p1.long() << (7 * c + k); bb2 |= p2.long() << (7 * c + k)
+            grid[:, 5 - k, c] = p1.float() - p2.float()
+    turn = (torch.randint(0, 2, (bsz,), device="cuda", generator=g) * 2 - 1).int()
+    sym = torch.randint(0, 2, (bsz,), device="cuda", generator=g).int()
+    gsym = torch.where(sym.view(-1, 1, 1) != 0, grid.flip(2), grid)
+    feat = torch.stack([(gsym * turn.view(-1, 1, 1) > 0).float(), (gsym * turn.view(-1, 1, 1) < 0).float(), torch.ones_like(gsym)], 1).contiguous()
+
+    class Pos(C.Structure):
+        _fields_ = [(n, vp) for n in ("bb_p1", "bb_p2", "turn", "sym")]
+    pos = Pos(bb1.data_ptr(), bb2.data_ptr(), turn.data_ptr(), sym.data_ptr())
+    L.az_nn_stem_folded_positions.argtypes = [C.POINTER(Pos), vp, vp, vp, C.c_int64, vp, vp, vp]
+    ya = torch.empty((bsz, 42, 64), dtype=torch.bfloat16, device="cuda"); yb = torch.empty_like(ya)
+    assert L.az_nn_stem_folded(feat.data_ptr(), net.stem_frag.data_ptr(), net.stem_pmap.data_ptr(), ya.data_ptr(), bsz, None, None, s) == 0
+    assert L.az_nn_stem_folded_positions(C.byref(pos), net.stem_frag.data_ptr(), net.stem_pmap.data_ptr(), yb.data_ptr(), bsz, None, None, s) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(ya.view(torch.int16), yb.view(torch.int16))
+    # compact batch: rows picked by gather, their number read on the device
+    rows = torch.randperm(bsz, device="cuda", generator=g)[:300].int().contiguous()
+    n_rows = torch.tensor([300], dtype=torch.int64, device="cuda")
+    yc = torch.full((bsz, 42, 64), 5.0, dtype=torch.bfloat16, device="cuda")
+    assert L.az_nn_stem_folded(feat.data_ptr(), net.stem_frag.data_ptr(), net.stem_pmap.data_ptr(), yc.data_ptr(), bsz, rows.data_ptr(), n_rows.data_ptr(), s) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(yc[:300].view(torch.int16), ya[rows.long()].view(torch.int16))
+    assert (yc[300:].float() == 5.0).all()
+    assert L.az_nn_stem_folded(None, net.stem_frag.data_ptr(), net.stem_pmap.data_ptr(), yc.data_ptr(), bsz, None, None, s) == 1
+
+
 def test_othello_conv_kernel_matches_torch(env):
     """az_nn_othello_conv (nn_othello.hip) against the same layer in torch fp32 with the reference's
     bf16 roundings, every supported geometry; batch sizes that leave workgroups with 0, 1 and

@@ -64,7 +64,11 @@ def stem_embed():
                        w32.data_ptr(), b.data_ptr(), y.data_ptr(), B, None, None, s)
 
 
-KERNELS = {"conv": conv, "stem": stem, "stem_embed": stem_embed, "attn": attn, "heads": heads}
+def stem_folded():
+    L.az_nn_stem_folded(feat.data_ptr(), net.stem_frag.data_ptr(), net.stem_pmap.data_ptr(), y.data_ptr(), B, None, None, s)
+
+
+KERNELS = {"conv": conv, "stem": stem, "stem_embed": stem_embed, "stem_folded": stem_folded, "attn": attn, "heads": heads}
 
 
 def timed(fn, n=20):
@@ -86,6 +90,8 @@ if len(sys.argv) > 1:
     for _ in range(int(sys.argv[3]) if len(sys.argv) > 3 else 5):
         fn()
     torch.cuda.synchronize()
+    if os.environ.get("PROBE_TIME"):
+        print("%-20s %7.1f us at %d leaves" % (sys.argv[1], timed(fn), B))
 else:
     for mode, name in ((0, "full"), (1, "no MFMA phase"), (2, "no epilogue/store"), (3, "staging + norm only")):
         L.az_nn_debug(mode)
