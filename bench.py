@@ -556,7 +556,11 @@ def main():
                 pair = roofline["empty_event_pair_us"] if roofline else 0.0
                 table = []
                 for idx, name, flops_leaf, bytes_leaf in (
-                        (0, "k_conv_block<32,..,EMBED> (stem + embedding)", 2.0 * 42 * 64 * 288, 504 + act),
+                        # the stem is a K = 18 (one k step of 32, table in a bf16 high and low part) GEMM on a 0/1 operand
+                        # built from two bitboards (nn_stem.hip): 24 + 8 bytes in, one sample's activations out
+                        ((0, "k_stem (embedding + stem convolution from the bitboards)", 2.0 * 2 * 48 * 64 * 32, 32 + act)
+                         if getattr(fast, "folded_stem", False) else
+                         (0, "k_conv_block<32,..,EMBED> (stem + embedding)", 2.0 * 42 * 64 * 288, 504 + act)),
                         (1, "k_conv_block<64,norm,residual> (x3 per forward)", 2.0 * 42 * 64 * 576, 2 * act),
                         (2, "k_attn_block", 2.0 * (42 * 196 * 64 + 2 * 4 * 42 * 42 * 16 + 42 * 64 * 64), 2 * act),
                         (3, "k_heads", 2.0 * (42 * 64 + 9 * 64 * 64 + 4 * 64 * 64 + 64 * 46), act + 7 + 44)):
