@@ -11,6 +11,7 @@ relative WDL, and the score utility atan(disc difference / score_scale) * 2/pi.
 """
 import ctypes as C
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -21,7 +22,8 @@ from src.fast_net import glue
 class _HeadsW(C.Structure):          # az_nn_othello_heads_weights (include/az_nn.h)
     _PTRS = ("board_w", "pass_norm_w", "pass_fc_w", "v_conv_w", "v_bn_s", "v_bn_b", "v_fc_w", "v_fc_b", "a_fc_wt", "a_fc_b",
              "a_norm_w", "a_out_w")
-    _fields_ = [(n, C.c_void_p) for n in _PTRS] + [(n, C.c_float) for n in ("board_b", "pass_fc_b", "a_out_b", "aux_to_score", "eps")]
+    _fields_ = ([(n, C.c_void_p) for n in _PTRS] + [(n, C.c_float) for n in ("board_b", "pass_fc_b", "a_out_b", "aux_to_score", "eps")] +
+                [("a_fc_w16", C.c_void_p)])
 
 
 class _ConvLayer(C.Structure):       # az_nn_othello_conv_layer
@@ -153,6 +155,12 @@ class FastOthelloNet(torch.nn.Module):
         h.v_bn_s, h.v_bn_b = t(self.v_bn[0].reshape(-1)), t(self.v_bn[1].reshape(-1))
         h.v_fc_w, h.v_fc_b = t(dh.value_out[5].weight), t(dh.value_out[5].bias)
         h.a_fc_wt, h.a_fc_b = t(dh.aux_out[1].weight.t()), t(dh.aux_out[1].bias)
+        if os.environ.get("AZ_OTH_HEADS_MFMA", "1") != "0":
+            # the same weight for the matrix cores: bf16 (as under autocast), input index in the bottleneck's NHWC order
+            # (the Linear takes the (8 channels, 8, 8) map flattened channel-major: in = 64 c + cell -> 8 cell + c)
+            w16 = dh.aux_out[1].weight.detach().to(dev, f32).reshape(512, 8, 64).transpose(1, 2).reshape(512, 512)
+            keep["a_fc_w16"] = w16.to(torch.bfloat16).contiguous()
+            h.a_fc_w16 = keep["a_fc_w16"].data_ptr()
         h.a_norm_w, h.a_out_w = t(dh.aux_out[2].weight), t(dh.aux_out[5].weight.reshape(-1))
         h.board_b, h.pass_fc_b, h.a_out_b = self.board_b, float(ph.pass_fc.bias.item()), float(dh.aux_out[5].bias.item())
         h.aux_to_score = float(self.aux_target_offset) / self.score_scale

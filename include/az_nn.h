@@ -233,6 +233,9 @@ typedef struct az_nn_othello_heads_weights {
     float board_b, pass_fc_b, a_out_b;
     float aux_to_score;                   /* aux_target_offset / score_scale (64 / 8) */
     float eps;                            /* the RMSNorms' epsilon (1e-5) */
+    const void *a_fc_w16;                 /* optional: aux_out[1].weight as bf16 (512 out, 512 in) with the INPUT index in the
+                                           * bottleneck's NHWC order (8 * cell + channel) - the layer then runs on the matrix
+                                           * cores, 16 samples per workgroup (k_oth_heads16); NULL: fp32 from a_fc_wt */
 } az_nn_othello_heads_weights;
 int az_nn_othello_embed(const az_nn_positions *positions, const uint8_t *mask, const void *embed_table, void *tokens,
                         int64_t batch, const int32_t *gather, const int64_t *batch_dev, void *stream);
