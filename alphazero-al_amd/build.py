@@ -43,9 +43,9 @@ def _run(cmd):
     subprocess.check_call(cmd)
 
 
-# nn_stem: MFMA results in VGPRs (its SiLU reads every accumulator element right away; from AGPRs that is one
-# v_accvgpr_read each)
-PER_FILE_FLAGS = {"nn_stem": ("-mllvm", "-amdgpu-mfma-vgpr-form=1")}
+# nn_stem, nn_heads: MFMA results in VGPRs (their vector code reads every accumulator element right away; from AGPRs
+# that is one v_accvgpr_read each; the other kernels get VGPR accumulators anyway)
+PER_FILE_FLAGS = {"nn_stem": ("-mllvm", "-amdgpu-mfma-vgpr-form=1"), "nn_heads": ("-mllvm", "-amdgpu-mfma-vgpr-form=1")}
 
 
 def build_engine(force=False):
