@@ -1355,6 +1355,21 @@ def test_othello_native_model_object(env):
     assert torch.equal(pc[idx], p[idx]) and torch.equal(wc[idx], w[idx]) and torch.equal(uc[idx], u[idx])
     rest = torch.ones(n, dtype=torch.bool, device="cuda"); rest[idx] = False
     assert pc[rest].abs().max().item() == 0.0
+    # the heads' first version (k_oth_heads: fp32 matvec, four samples per workgroup) against the one in use
+    # (k_oth_heads16: the auxiliary Linear on the matrix cores with bf16 weights, one wavefront per sample for the rest):
+    # same policy and value to fp32 rounding, the utility within what bf16 weights of one 512 x 512 layer cost; a batch
+    # that does not fill the last workgroup of sixteen
+    import os
+    os.environ["AZ_OTH_HEADS_MFMA"] = "0"
+    try:
+        twin_old = FastOthelloNet(net)
+        model_new, model = model, twin_old.native_model()
+        po, wo, uo = run(boards, turns, np.zeros(n, np.int32), masks)
+    finally:
+        del os.environ["AZ_OTH_HEADS_MFMA"]
+        model = model_new
+    assert (p - po).abs().max().item() < 2e-6 and (w - wo).abs().max().item() < 2e-6, ((p - po).abs().max().item(), (w - wo).abs().max().item())
+    assert (u - uo).abs().max().item() < 5e-3, (u - uo).abs().max().item()
     # the device loop: above 512 trees the whole search is one native call for Othello as well
     b600 = np.tile(boards, (4, 1, 1)); t600 = np.tile(turns, 4)
     wr = env["W"].BatchedMCTS(600, 1.4, 800, 0.3, 24, noise_epsilon=0.25, fpu_reduction=0.2, use_symmetry=True,
