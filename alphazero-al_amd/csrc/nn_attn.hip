@@ -88,7 +88,7 @@ __device__ __forceinline__ float col_max(float v)
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k((a), (b), (c), 0, 0, 0)
 
 // qkvg: (196, 64) row-major [out][in]: rows 0-63 Q, 64-127 K, 128-191 V, 192-195 gate
-template <int MINB>      // workgroups per CU the register budget is cut for (2: 190 VGPRs, no spills; 3: 168 with 25 spilled)
+template <int MINB>      // workgroups per CU the register budget is cut for (2: 190 VGPRs, no spills; 3, the default: 168 + 13 spilled)
 __global__ void __launch_bounds__(256, MINB) k_attn_block(const uint16_t *x, const uint16_t *pre_w, const uint16_t *qkvg,
                                                     const uint16_t *qn_w, const uint16_t *kn_w, const uint16_t *o_w,
                                                     uint16_t *y, int64_t B, float eps, const int64_t *batch_dev)
@@ -120,6 +120,20 @@ __global__ void __launch_bounds__(256, MINB) k_attn_block(const uint16_t *x, con
     for (int i = threadIdx.x; i < 4 * HEADS * 64; i += blockDim.x) {
         const int f = i >> 6, l = i & 63, ot = f / HEADS, h = f % HEADS;
         s_w16[i] = *reinterpret_cast<const V4 *>(o_w + (ot * 16 + (l & 15)) * C + h * HD + 4 * (l >> 4));
+    }
+    // MINB >= 3 (three or four wavefronts per SIMD): what the two-per-SIMD kernel keeps in registers across a whole
+    // sample - the sigmoid gates of every (token, head), the pre-norm weight, the q / k norm weights - lives in LDS
+    // instead (36 registers: the variant then fits its budget without scratch)
+    constexpr bool LEAN = MINB >= 3;
+    __shared__ f32x4 s_gate[LEAN ? 4 * TT * 64 : 1];      // [wave][token tile][lane]: gate of heads 0..3
+    __shared__ float s_pw[LEAN ? C : 1];                   // pre-norm weight
+    __shared__ float s_qk[LEAN ? 2 * HD : 1];              // q norm weight x QSCALE, k norm weight
+    if (LEAN) {
+        if (threadIdx.x < C) s_pw[threadIdx.x] = bf1(pre_w + threadIdx.x);
+        if (threadIdx.x < HD) {
+            s_qk[threadIdx.x] = bf1(qn_w + threadIdx.x) * (0.25f * 1.44269504f);
+            s_qk[HD + threadIdx.x] = bf1(kn_w + threadIdx.x);
+        }
     }
     __syncthreads();
     // (the head loop below is not unrolled and indexes these by the runtime head number, so the
@@ -181,7 +195,8 @@ __global__ void __launch_bounds__(256, MINB) k_attn_block(const uint16_t *x, con
                 V8 o;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const f32x2 hv = f[s][i] * f32x2{r, r} * pw[s][i];
+                    const f32x2 pwv = LEAN ? *reinterpret_cast<const f32x2 *>(&s_pw[32 * s + 8 * l4 + 2 * i]) : pw[s][i];
+                    const f32x2 hv = f[s][i] * f32x2{r, r} * pwv;
                     o.w[i] = pack2(hv.x, hv.y);
                 }
                 hf[tt][s] = as_bf16x8(o);
@@ -199,6 +214,7 @@ __global__ void __launch_bounds__(256, MINB) k_attn_block(const uint16_t *x, con
             for (int h = 0; h < HEADS; ++h) {
                 gate[tt][h] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * g[h]));
             }
+            if (LEAN) s_gate[(wave * TT + tt) * 64 + lane] = f32x4{gate[tt][0], gate[tt][1], gate[tt][2], gate[tt][3]};
         }
 
         f32x4 out[4][TT];
@@ -227,7 +243,11 @@ __global__ void __launch_bounds__(256, MINB) k_attn_block(const uint16_t *x, con
                 const float qs = col_sum(qq.x + qq.y), ks = col_sum(kk.x + kk.y);
                 const float qr = rsqrtf(qs * (1.0f / HD) + eps), kr = rsqrtf(ks * (1.0f / HD) + eps);
 #pragma unroll
-                for (int r = 0; r < 2; ++r) { q2[r] = q2[r] * f32x2{qr, qr} * qnw[r]; k2[r] = k2[r] * f32x2{kr, kr} * knw[r]; }
+                for (int r = 0; r < 2; ++r) {
+                    const f32x2 qw = LEAN ? *reinterpret_cast<const f32x2 *>(&s_qk[4 * l4 + 2 * r]) : qnw[r];
+                    const f32x2 kw = LEAN ? *reinterpret_cast<const f32x2 *>(&s_qk[HD + 4 * l4 + 2 * r]) : knw[r];
+                    q2[r] = q2[r] * f32x2{qr, qr} * qw; k2[r] = k2[r] * f32x2{kr, kr} * kw;
+                }
                 qb[tt] = to_s16x4(f32x4{q2[0].x, q2[0].y, q2[1].x, q2[1].y});
                 kb[tt] = to_s16x4(f32x4{k2[0].x, k2[0].y, k2[1].x, k2[1].y});
                 vb[tt] = to_s16x4(v);
@@ -282,7 +302,8 @@ __global__ void __launch_bounds__(256, MINB) k_attn_block(const uint16_t *x, con
                     den = col_sum(den2.x + den2.y);
                 }
                 // normalise after the product: O^T = (V^T . E^T) / den, one scale per output element
-                const float gq = h == 0 ? gate[qt][0] : (h == 1 ? gate[qt][1] : (h == 2 ? gate[qt][2] : gate[qt][3]));
+                const float gq = LEAN ? reinterpret_cast<const float *>(&s_gate[(wave * TT + qt) * 64 + lane])[h]
+                                      : (h == 0 ? gate[qt][0] : (h == 1 ? gate[qt][1] : (h == 2 ? gate[qt][2] : gate[qt][3])));
                 const float scale = __builtin_amdgcn_rcpf(den) * gq;
                 f32x4 o = zero;                                  // O^T rows = d, column = query
 #pragma unroll
@@ -326,7 +347,9 @@ int az_nn_attn_block(const void *x, const void *prenorm_w, const void *qkvg_w, c
     if (batch <= 0) return 1;
     const int64_t wgs = (batch + 3) / 4;
     const unsigned grid = static_cast<unsigned>(wgs < 1024 ? wgs : 1024);
-    static const int occ = [] { const char *e = getenv("AZ_ATTN_OCC"); const int v = e ? atoi(e) : 2; return (v == 3 || v == 4) ? v : 2; }();
+    // three wavefronts per SIMD (168 registers, the per-sample constants and the gates in LDS: 169 us against 179 at two
+    // per SIMD with everything in 190 registers; AZ_ATTN_OCC=2 / 4 select the other register budgets)
+    static const int occ = [] { const char *e = getenv("AZ_ATTN_OCC"); const int v = e ? atoi(e) : 3; return (v == 2 || v == 4) ? v : 3; }();
     auto go = [&](auto kern, unsigned g) {
         hipLaunchKernelGGL(kern, dim3(g), dim3(256), 0, static_cast<hipStream_t>(stream),
                            static_cast<const uint16_t *>(x), static_cast<const uint16_t *>(prenorm_w),
