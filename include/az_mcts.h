@@ -131,7 +131,10 @@ int az_mcts_get_all_root_stats(az_mcts *m, float *out);
  * (grows the arenas if needed; synchronises).  Reserve PER SEARCH: the host-side occupancy bound restarts
  * from the figure each az_mcts_dev_prune_roots reports, so room reserved before a re-rooting for
  * searches enqueued after it is forgotten - call this once for every search, after the re-rooting that
- * precedes it (as selfplay.py / fused.py do). */
+ * precedes it (as selfplay.py / fused.py do).  The room is sims_per_tree x the game's largest block of children
+ * (Connect4 7; Othello 33, the most legal moves of a position REACHABLE in play): imported Othello positions with
+ * more moves are searched correctly but can outrun the reservation - an expansion that does not fit is dropped and
+ * raises the sticky error word (az_mcts_dev_check: arena full), never a store out of range. */
 int az_mcts_dev_prepare(az_mcts *m, int K, int64_t sims_per_tree);
 /* The same for a caller whose work on these trees is all on ONE stream: when the call has to look
  * at the trees (their fill), move a buffer or refresh a table, it waits for that stream only
