@@ -102,10 +102,13 @@ def self_launch(args):
     child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
     line = None
     for out in child.stdout:
-        sys.stdout.write(out)
-        sys.stdout.flush()
+        # stdout of this process carries ONE line, the bench line; whatever else the ranks or their libraries print
+        # on stdout (gloo's connection messages in a rehearsal) goes to stderr
         if out.startswith("{"):
             line = out
+        else:
+            sys.stderr.write(out)
+            sys.stderr.flush()
     rc = child.wait()
     if rc != 0:
         raise SystemExit("bench.py: the %d-rank run exited with code %d" % (args.gpus, rc))
@@ -115,6 +118,8 @@ def self_launch(args):
         seen = None
     if seen != args.gpus:
         raise SystemExit("bench.py: asked for %d GPUs, the run reported n_gpus=%r" % (args.gpus, seen))
+    sys.stdout.write(line)
+    sys.stdout.flush()
     return 0
 
 
