@@ -165,10 +165,12 @@ def _compare(tape, counts, stats):
 
 
 @pytest.mark.parametrize("native", [True, False], ids=["native_loop", "python_loop"])
-@pytest.mark.parametrize("n,K", [(50, 4), (41, 1), (200, 4)])
+@pytest.mark.parametrize("n,K", [(50, 4), (41, 1), (200, 4), (43, 2), (61, 3), (73, 8)])
 def test_connect4_device_loop_reference_stream(env, native, n, K):
     """ACTOR_CFG (the configuration bench.py times) with re-rooting between plies; openings up to 30
-    plies deep so that terminal leaves (no symmetry draw, BatchedMCTS.h:148) and finished games occur."""
+    plies deep so that terminal leaves (no symmetry draw, BatchedMCTS.h:148) and finished games occur.
+    K = 2, 3, 8: the FUSED instantiations of k_backprop_spread for two, four and eight lane groups per tree
+    (K = 8 selects with k_select8)."""
     rng = np.random.default_rng(1000 + n + K)
     boards, turns = S.random_openings(rng, 96, 30)
     cfg = dict(S.ACTOR_CFG, c_base=5.0 * n)
