@@ -462,6 +462,12 @@ __global__ void __launch_bounds__(256, 2) k_conv_block(const uint16_t *x, const 
             if (with_epi) epi_end(e);
         };
         if (!(dbg & 1)) {
+            // az_nn_debug bit 5: the matrix phase at a higher issue priority than the other workgroup's load / store phases
+            if ((dbg >> 5) & 3) {
+                if (((dbg >> 5) & 3) == 1) __builtin_amdgcn_s_setprio(1);
+                else if (((dbg >> 5) & 3) == 2) __builtin_amdgcn_s_setprio(2);
+                else __builtin_amdgcn_s_setprio(3);
+            }
             f32x4 acc_a[2], acc_b[2];
             block(0, acc_a, false, acc_b);
             // unrolled: the tile number is a constant in every read's offset field; the accumulator sets alternate
@@ -477,6 +483,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_block(const uint16_t *x, const 
                 for (int step = 0; step < 36; ++step) epi_step(step, acc_b, e);
                 epi_end(e);
             }
+            if ((dbg >> 5) & 3) __builtin_amdgcn_s_setprio(0);
         }
         // the staged tile has landed; every wave is done with img and has written its outputs
         stamp(2);
@@ -527,13 +534,15 @@ int launch(const void *x, const void *w, const void *bias, const void *gamma, co
             fprintf(stderr, "[az_nn] conv block C_in=%d: %zu B LDS, %d workgroups per CU\n", CIN, smem, per_cu);
         }
     }
+    // issue priority of the matrix phase over the other workgroup's load / store phases (s_setprio 0..3; AZ_NN_CONV_PRIO)
+    static const int prio = [] { const char *e = getenv("AZ_NN_CONV_PRIO"); const int v = e ? atoi(e) : 1; return v < 0 || v > 3 ? 1 : v; }();
     const int64_t ntiles = (B + TS - 1) / TS;
     static const int64_t max_grid = getenv("AZ_NN_CONV_GRID") ? atoll(getenv("AZ_NN_CONV_GRID")) : 512;   // two workgroups per CU
     const unsigned grid = static_cast<unsigned>(ntiles < max_grid ? ntiles : max_grid);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, static_cast<const uint16_t *>(x),
                        static_cast<const uint16_t *>(w), static_cast<const uint16_t *>(bias),
                        static_cast<const uint16_t *>(gamma), static_cast<const uint16_t *>(beta),
-                       static_cast<uint16_t *>(y), B, eps, g_dbg, batch_dev, em);
+                       static_cast<uint16_t *>(y), B, eps, g_dbg | (((g_dbg >> 5) & 3) ? 0 : (prio << 5)), batch_dev, em);
     return 0;
 }
 

@@ -173,6 +173,8 @@ __global__ void __launch_bounds__(256, 2) k_oth_conv(const uint16_t *x, const ui
                 for (int i = 0; i < 4; ++i)
                     acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bq[t], acc[i][t], 0, 0, 0);
         };
+        // the matrix phase at a higher issue priority than the partner workgroup's copy / output phases (AZ_OTH_DEBUG bit 3: off)
+        if (!(dbg & 8)) __builtin_amdgcn_s_setprio(1);
         if (dbg & 2) {
             // timing experiment (AZ_OTH_DEBUG=2, results wrong): no MFMA phase - what the copy and output phases cost alone
         } else if constexpr (KPT >= 2) {
@@ -225,6 +227,7 @@ __global__ void __launch_bounds__(256, 2) k_oth_conv(const uint16_t *x, const ui
                 multiply(a, bq);
             }
         }
+        if (!(dbg & 8)) __builtin_amdgcn_s_setprio(0);
         __syncthreads();                       // every wavefront is done with the image
 
         // ---- accumulators -> affine -> bf16 -> token-major stage in LDS (16-byte chunks swizzled by token)
